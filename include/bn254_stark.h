@@ -1,0 +1,127 @@
+/*
+ * bn254_stark.h - C ABI of the MI355X-native prover for the BN254 scalar-multiplication STARKs.
+ *
+ * Drop-in boundary: one call replaces the body of the reference's witness generator
+ *   G1StarkProofGenerator::run_once   src/generators/g1/stark_proof.rs:136-179
+ * namely lines :143-163 (outputs = s*x+offset, generate_trace, starks::common::prover::prove).  The caller
+ * (a Rust shim) keeps get_witness / set_witness / verify / set_stark_proof_target.
+ * G2 (src/generators/g2/stark_proof.rs:136-179) and Fq-exp (src/generators/fq/stark_proof.rs:135-178)
+ * entry points have the same shape.
+ *
+ * Wire formats (all little-endian u64 words, canonical = reduced, non-Montgomery):
+ *   scalar  : 4 words, any 256-bit value (NOT reduced modulo the group order; common/utils.rs:21-25)
+ *   Fq      : 4 words, value < p
+ *   G1 point: 8 words = x, y (affine, never infinity; src/curves/g1.rs:170-174)
+ *   G2 point: 16 words = x.c0, x.c1, y.c0, y.c1
+ *   Goldilocks element: 1 word < 2^64 - 2^32 + 1; extension element: 2 words (c0, c1)
+ *   Poseidon digest: 4 words
+ *
+ * Proof layout returned by bn254s_proof_words() - field order of starky's StarkProofWithMetadata
+ * (reference src/starks/common/prover.rs:66-71), W = trace width, A = auxiliary polys, L = FRI layers,
+ * P = lde_bits - cap_height Merkle path length of the initial trees:
+ *   trace_cap[16*4] aux_cap[16*4] quotient_cap[16*4]
+ *   openings: local_values[W*2] next_values[W*2] auxiliary_polys[A*2] auxiliary_polys_next[A*2]
+ *             ctl_zs_first[4] quotient_polys[4*2]
+ *   commit_phase_merkle_caps[L][16*4]
+ *   query_round_proofs[84]: for oracle in (trace, aux, quotient): leaf[width] path[P*4];
+ *                           for layer l: evals[16*2] path[P_l*4]
+ *   final_poly[len*2]  pow_witness[1]  init_challenger_state[12]
+ *
+ * Errors: every function returns 0 on success or a negative BN254S_E_* code; the reference panics
+ * (unwrap at stark_proof.rs:163,172), the Rust shim maps non-zero to panic!.
+ * Threading: one call at a time per context; any number of contexts (one per GPU / per host thread).
+ */
+#ifndef BN254_STARK_H
+#define BN254_STARK_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BN254S_ABI_VERSION 1
+
+enum {
+  BN254S_OK = 0,
+  BN254S_E_INVALID_ARG = -1,
+  BN254S_E_HIP = -2,            /* HIP runtime / launch failure, see bn254s_last_error */
+  BN254S_E_OOM = -3,
+  BN254S_E_INVALID_POINT = -4,  /* a + (-a) met during the double-and-add chain (generate_g1_add, add.rs:49-51) */
+  BN254S_E_UNSUPPORTED = -5,    /* shape not implemented by this build */
+  BN254S_E_TRANSCRIPT = -6      /* opening point inside the subgroup (starky "Opening point is in the subgroup") */
+};
+
+typedef struct bn254s_ctx bn254s_ctx;
+typedef struct bn254s_proof bn254s_proof;
+
+/* StarkConfig::standard_fast_config() + min_rows (stark_proof.rs:152-154). POD, versioned by struct_size. */
+typedef struct bn254s_params {
+  uint32_t struct_size;
+  uint32_t security_bits;   /* 100 */
+  uint32_t num_challenges;  /* 2 */
+  uint32_t rate_bits;       /* 1 */
+  uint32_t cap_height;      /* 4 */
+  uint32_t pow_bits;        /* 16 */
+  uint32_t arity_bits;      /* 4  (ConstantArityBits(4, 5)) */
+  uint32_t final_poly_bits; /* 5 */
+  uint32_t num_queries;     /* 84 */
+  uint32_t min_rows_log2;   /* 16 */
+} bn254s_params;
+
+void bn254s_params_default(bn254s_params* p);
+int bn254s_abi_version(void);
+
+/* One context per GPU: owns the HIP stream(s), twiddle tables and the pooled device workspace. */
+int bn254s_ctx_create(int device_id, bn254s_ctx** out);
+void bn254s_ctx_destroy(bn254s_ctx* ctx);
+const char* bn254s_last_error(const bn254s_ctx* ctx);
+
+/* Prove n G1 scalar multiplications s_i * x_i + offset_i in ONE STARK (timestamps 0..n-1), like
+ * G1ScalarMulStark::generate_trace + prove (scalar_mul_stark.rs:55-69, common/prover.rs:18-72).
+ * rows = max(2^min_rows_log2, 512 n) rounded up to a power of two. */
+int bn254s_prove_g1(bn254s_ctx* ctx, const bn254s_params* params, const uint64_t* scalars /* n x 4 */,
+                    const uint64_t* x /* n x 8 */, const uint64_t* offset /* n x 8 */, size_t n, bn254s_proof** out);
+
+/* Throughput entry point: n_total jobs are cut into ceil(n_total / per_proof) independent proofs
+ * (per_proof = 128 gives the reference test shape, 2^16 rows) that are pipelined on the GPU.
+ * proofs_out must have room for that many pointers. */
+int bn254s_prove_g1_batch(bn254s_ctx* ctx, const bn254s_params* params, const uint64_t* scalars, const uint64_t* x,
+                          const uint64_t* offset, size_t n_total, size_t per_proof, bn254s_proof** proofs_out);
+
+/* Same for G2 (points n x 16) and Fq exponentiation x^s (x n x 4): src/generators/{g2,fq}/stark_proof.rs. */
+int bn254s_prove_g2(bn254s_ctx* ctx, const bn254s_params* params, const uint64_t* scalars, const uint64_t* x,
+                    const uint64_t* offset, size_t n, bn254s_proof** out);
+int bn254s_prove_fq_exp(bn254s_ctx* ctx, const bn254s_params* params, const uint64_t* scalars, const uint64_t* x,
+                        const uint64_t* offset /* n x 4 */, size_t n, bn254s_proof** out);
+
+/* Proof accessors.  Pointers stay valid until bn254s_proof_free. */
+int bn254s_proof_words(const bn254s_proof* p, const uint64_t** data, size_t* len);
+int bn254s_proof_degree_bits(const bn254s_proof* p);
+/* n x (8 | 16 | 4) words: the outputs s*x+offset (what run_once writes with set_witness at :147-149). */
+int bn254s_proof_outputs(const bn254s_proof* p, const uint64_t** data, size_t* len);
+/* Per-stage GPU milliseconds of the call that produced the proof (names via bn254s_stage_name). */
+int bn254s_proof_stage_ms(const bn254s_proof* p, const float** ms, size_t* n_stages);
+const char* bn254s_stage_name(size_t stage);
+size_t bn254s_proof_serialize(const bn254s_proof* p, uint8_t* buf, size_t cap); /* LE bytes of the word layout */
+void bn254s_proof_free(bn254s_proof* p);
+
+/* ---- kernel-level entry points (parity tests and bench.py's roofline leg) ------------------------------ */
+/* PolynomialBatch::from_values on host column-major values[C][2^16]: outputs (any may be NULL)
+ * coeffs[C][N], lde[C][2N] in Merkle-leaf (bit-reversed) order, cap[16*4]. */
+int bn254s_commit_values(bn254s_ctx* ctx, const uint64_t* values, size_t ncols, uint64_t* coeffs, uint64_t* lde,
+                         uint64_t* cap);
+/* Times `iters` runs of the NTT/LDE stage (iNTT + both coset NTTs) on ncols resident columns of 2^16
+ * synthetic values; returns average milliseconds per run through *ms (HIP events on the kernels' stream). */
+int bn254s_bench_ntt(bn254s_ctx* ctx, size_t ncols, int iters, float* ms);
+/* Poseidon permutation of `n` 12-word states in place (host buffer). */
+int bn254s_poseidon_permute(bn254s_ctx* ctx, uint64_t* states, size_t n);
+/* Trace generation only: column-major trace[W][rows] copied to the host buffer. */
+int bn254s_g1_generate_trace(bn254s_ctx* ctx, const uint64_t* scalars, const uint64_t* x, const uint64_t* offset,
+                             size_t n, uint32_t min_rows_log2, uint64_t* trace_out, uint64_t* outputs);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BN254_STARK_H */

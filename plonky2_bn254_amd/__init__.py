@@ -1,0 +1,8 @@
+"""MI355X-native prover for the BN254 scalar-multiplication STARKs of plonky2_bn254.
+
+The product is `libbn254stark.so` (hand-written HIP kernels for gfx950 behind the C ABI declared in
+include/bn254_stark.h).  This package is the thin host-side mirror used by tests and bench.py:
+`Context.prove_g1(...)` corresponds to the body of the reference's
+`G1StarkProofGenerator::run_once` (src/generators/g1/stark_proof.rs:136-179, lines 143-163).
+"""
+from .lib import Context, Proof, load_library, LibraryMissing, default_params  # noqa: F401

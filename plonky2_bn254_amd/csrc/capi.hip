@@ -1,0 +1,144 @@
+// C ABI of libbn254stark.so (include/bn254_stark.h): context management and kernel-level entry points.
+// The proving entry points live in prover.hip.
+#include "ctx.h"
+#include "merkle.h"
+#include "poseidon_dev.h"
+
+extern "C" {
+
+int bn254s_abi_version(void) { return BN254S_ABI_VERSION; }
+
+void bn254s_params_default(bn254s_params* p) {
+  p->struct_size = sizeof(bn254s_params);
+  p->security_bits = 100;
+  p->num_challenges = 2;
+  p->rate_bits = 1;
+  p->cap_height = 4;
+  p->pow_bits = 16;
+  p->arity_bits = 4;
+  p->final_poly_bits = 5;
+  p->num_queries = 84;
+  p->min_rows_log2 = 16;
+}
+
+int bn254s_ctx_create(int device_id, bn254s_ctx** out) {
+  if (!out) return BN254S_E_INVALID_ARG;
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device_id < 0 || device_id >= ndev) return BN254S_E_HIP;
+  if (hipSetDevice(device_id) != hipSuccess) return BN254S_E_HIP;
+  bn254s_ctx* c = new bn254s_ctx();
+  c->device = device_id;
+  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+    delete c;
+    return BN254S_E_HIP;
+  }
+  if (ntt_tables_init(&c->ntt) != 0) {
+    delete c;
+    return BN254S_E_OOM;
+  }
+  *out = c;
+  return BN254S_OK;
+}
+
+void bn254s_ctx_destroy(bn254s_ctx* c) {
+  if (!c) return;
+  hipSetDevice(c->device);
+  hipStreamSynchronize(c->stream);
+  for (auto& kv : c->pool) hipFree(kv.second.first);
+  ntt_tables_free(&c->ntt);
+  hipStreamDestroy(c->stream);
+  delete c;
+}
+
+const char* bn254s_last_error(const bn254s_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+int bn254s_commit_values(bn254s_ctx* c, const uint64_t* values, size_t ncols, uint64_t* coeffs, uint64_t* lde,
+                         uint64_t* cap) {
+  if (!c || !values || ncols == 0) return BN254S_E_INVALID_ARG;
+  HIP_TRY(c, hipSetDevice(c->device));
+  const size_t N = NTT_N;
+  u64* d_vals = c->words("cv.vals", ncols * N);
+  u64* d_tmp = c->words("cv.tmp", ncols * N);
+  u64* d_lde = c->words("cv.lde", ncols * 2 * N);
+  u64* d_tree = c->words("cv.tree", merkle_tree_digests(17, 4) * 4);
+  if (!d_vals || !d_tmp || !d_lde || !d_tree) return BN254S_E_OOM;
+  HIP_TRY(c, hipMemcpyAsync(d_vals, values, ncols * N * 8, hipMemcpyHostToDevice, c->stream));
+  ntt_inverse(&c->ntt, d_vals, d_vals, d_tmp, (int)ncols, c->stream);
+  ntt_lde(&c->ntt, d_vals, d_lde, d_tmp, (int)ncols, c->stream);
+  merkle_build(d_lde, 1, 2 * N, (int)ncols, 17, 4, d_tree, c->stream);
+  HIP_TRY(c, hipGetLastError());
+  if (coeffs) HIP_TRY(c, hipMemcpyAsync(coeffs, d_vals, ncols * N * 8, hipMemcpyDeviceToHost, c->stream));
+  if (lde) HIP_TRY(c, hipMemcpyAsync(lde, d_lde, ncols * 2 * N * 8, hipMemcpyDeviceToHost, c->stream));
+  if (cap)
+    HIP_TRY(c, hipMemcpyAsync(cap, d_tree + 4 * merkle_level_offset(17, 13), 16 * 32, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return BN254S_OK;
+}
+
+__global__ void k_fill_pseudo(u64* p, size_t n, u64 seed) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  u64 z = seed + i * 0x9E3779B97F4A7C15ULL;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+  z ^= z >> 31;
+  p[i] = z >= GL_P ? z - GL_P : z;
+}
+
+int bn254s_bench_ntt(bn254s_ctx* c, size_t ncols, int iters, float* ms) {
+  if (!c || !ms || ncols == 0 || iters <= 0) return BN254S_E_INVALID_ARG;
+  HIP_TRY(c, hipSetDevice(c->device));
+  const size_t N = NTT_N;
+  u64* d_vals = c->words("cv.vals", ncols * N);
+  u64* d_tmp = c->words("cv.tmp", ncols * N);
+  u64* d_lde = c->words("cv.lde", ncols * 2 * N);
+  if (!d_vals || !d_tmp || !d_lde) return BN254S_E_OOM;
+  size_t n = ncols * N;
+  k_fill_pseudo<<<(unsigned)((n + 255) / 256), 256, 0, c->stream>>>(d_vals, n, 0x1234);
+  hipEvent_t e0, e1;
+  HIP_TRY(c, hipEventCreate(&e0));
+  HIP_TRY(c, hipEventCreate(&e1));
+  // warm-up
+  ntt_inverse(&c->ntt, d_vals, d_vals, d_tmp, (int)ncols, c->stream);
+  ntt_lde(&c->ntt, d_vals, d_lde, d_tmp, (int)ncols, c->stream);
+  HIP_TRY(c, hipEventRecord(e0, c->stream));
+  for (int it = 0; it < iters; it++) {
+    ntt_inverse(&c->ntt, d_vals, d_vals, d_tmp, (int)ncols, c->stream);
+    ntt_lde(&c->ntt, d_vals, d_lde, d_tmp, (int)ncols, c->stream);
+  }
+  HIP_TRY(c, hipEventRecord(e1, c->stream));
+  HIP_TRY(c, hipEventSynchronize(e1));
+  float t = 0;
+  HIP_TRY(c, hipEventElapsedTime(&t, e0, e1));
+  *ms = t / iters;
+  hipEventDestroy(e0);
+  hipEventDestroy(e1);
+  HIP_TRY(c, hipGetLastError());
+  return BN254S_OK;
+}
+
+__global__ void k_poseidon_states(u64* st, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  u64 s[12];
+  for (int k = 0; k < 12; k++) s[k] = st[12 * i + k];
+  poseidon_permute(s);
+  for (int k = 0; k < 12; k++) st[12 * i + k] = s[k];
+}
+
+int bn254s_poseidon_permute(bn254s_ctx* c, uint64_t* states, size_t n) {
+  if (!c || !states) return BN254S_E_INVALID_ARG;
+  if (n == 0) return BN254S_OK;
+  HIP_TRY(c, hipSetDevice(c->device));
+  u64* d = c->words("pp.states", 12 * n);
+  if (!d) return BN254S_E_OOM;
+  HIP_TRY(c, hipMemcpyAsync(d, states, 96 * n, hipMemcpyHostToDevice, c->stream));
+  k_poseidon_states<<<(unsigned)((n + 63) / 64), 64, 0, c->stream>>>(d, n);
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipMemcpyAsync(states, d, 96 * n, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return BN254S_OK;
+}
+
+}  // extern "C"

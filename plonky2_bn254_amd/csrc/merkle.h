@@ -1,0 +1,17 @@
+// Poseidon Merkle commitment kernels (merkle.hip): leaf hashing + tree levels with a cap.
+#pragma once
+#include "gl_dev.h"
+
+// Digest storage: 4 consecutive u64 per digest.  A tree over 2^L leaves with cap height H keeps levels
+// 0..L-H concatenated: level l starts at digest index merkle_level_offset(L, l) and has 2^(L-l) digests.
+static inline size_t merkle_level_offset(int log_leaves, int level) {
+  size_t off = 0;
+  for (int l = 0; l < level; l++) off += (size_t)1 << (log_leaves - l);
+  return off;
+}
+static inline size_t merkle_tree_digests(int log_leaves, int cap_height) { return merkle_level_offset(log_leaves, log_leaves - cap_height + 1); }
+
+// Hash 2^log_leaves leaves of `leaf_len` elements (element e of leaf j at data[j*leaf_stride + e*elem_stride])
+// and build all levels up to the cap.  tree must hold merkle_tree_digests() * 4 words.
+void merkle_build(const u64* data, size_t leaf_stride, size_t elem_stride, int leaf_len, int log_leaves, int cap_height,
+                  u64* tree, hipStream_t s);

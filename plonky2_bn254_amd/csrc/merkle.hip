@@ -1,0 +1,61 @@
+// Poseidon-Goldilocks Merkle commitment for gfx950.
+// Replaces plonky2 `MerkleTree::new(leaves, cap_height)` inside PolynomialBatch::from_coeffs (reached from
+// reference src/starks/common/prover.rs:31-38) and the FRI commit-phase trees: leaf digest =
+// hash_or_noop(leaf) (leaves of <= 4 elements are not hashed), inner nodes = two_to_one, cap = the 2^cap_height
+// nodes at that depth.  One lane per leaf, sponge state in VGPRs, round constants read through the
+// scalar/constant path; leaves are read column-major so that consecutive lanes touch consecutive words.
+#include "merkle.h"
+#include "poseidon_dev.h"
+
+__global__ __launch_bounds__(256) void k_leaf_hash(const u64* __restrict__ data, size_t leaf_stride, size_t elem_stride,
+                                                   int leaf_len, size_t n_leaves, u64* __restrict__ digests) {
+  size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n_leaves) return;
+  const u64* p = data + j * leaf_stride;
+  u64 s[12];
+#pragma unroll
+  for (int i = 0; i < 12; i++) s[i] = 0;
+  if (leaf_len <= 4) {
+    for (int i = 0; i < leaf_len; i++) s[i] = p[(size_t)i * elem_stride];
+  } else {
+    int c = 0;
+    for (; c + 8 <= leaf_len; c += 8) {
+#pragma unroll
+      for (int i = 0; i < 8; i++) s[i] = p[(size_t)(c + i) * elem_stride];
+      poseidon_permute(s);
+    }
+    if (c < leaf_len) {
+#pragma unroll
+      for (int i = 0; i < 8; i++)
+        if (c + i < leaf_len) s[i] = p[(size_t)(c + i) * elem_stride];
+      poseidon_permute(s);
+    }
+  }
+  ulonglong2* o = reinterpret_cast<ulonglong2*>(digests + 4 * j);
+  o[0] = make_ulonglong2(s[0], s[1]);
+  o[1] = make_ulonglong2(s[2], s[3]);
+}
+
+__global__ __launch_bounds__(256) void k_merkle_level(const u64* __restrict__ in, u64* __restrict__ out, size_t n_out) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_out) return;
+  const ulonglong2* p = reinterpret_cast<const ulonglong2*>(in + 8 * i);
+  ulonglong2 a = p[0], b = p[1], c = p[2], d = p[3];
+  u64 s[12] = {a.x, a.y, b.x, b.y, c.x, c.y, d.x, d.y, 0, 0, 0, 0};
+  poseidon_permute(s);
+  ulonglong2* o = reinterpret_cast<ulonglong2*>(out + 4 * i);
+  o[0] = make_ulonglong2(s[0], s[1]);
+  o[1] = make_ulonglong2(s[2], s[3]);
+}
+
+void merkle_build(const u64* data, size_t leaf_stride, size_t elem_stride, int leaf_len, int log_leaves, int cap_height,
+                  u64* tree, hipStream_t s) {
+  size_t n = (size_t)1 << log_leaves;
+  k_leaf_hash<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(data, leaf_stride, elem_stride, leaf_len, n, tree);
+  for (int l = 0; l < log_leaves - cap_height; l++) {
+    size_t n_out = (size_t)1 << (log_leaves - l - 1);
+    const u64* in = tree + 4 * merkle_level_offset(log_leaves, l);
+    u64* out = tree + 4 * merkle_level_offset(log_leaves, l + 1);
+    k_merkle_level<<<(unsigned)((n_out + 255) / 256), 256, 0, s>>>(in, out, n_out);
+  }
+}

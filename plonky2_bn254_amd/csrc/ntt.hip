@@ -1,0 +1,250 @@
+// Goldilocks radix-2^16 NTT / low-degree extension kernels for gfx950 (the north-star kernel).
+//
+// What it replaces: plonky2 `PolynomialBatch::from_values` / `from_coeffs` as called by the reference at
+// src/starks/common/prover.rs:31-38 (per column: iFFT(N) -> zero-pad to 2N -> coset FFT with shift g ->
+// rows in bit-reversed order), and `coset_ifft` in starky's compute_quotient_polys.
+//
+// Design (DESIGN.md "K-ntt"): a size-2^16 transform is a 256 x 256 four-step.  Each 256-point DFT is two
+// radix-16 passes held in registers (16 values per thread) with one LDS transpose in between.  All
+// 16th roots of unity in Goldilocks are powers of two (w_16 = 2^12), so the radix-16 butterflies use
+// shifts only; full 64-bit modular multiplications are needed just for the inter-pass twiddles.
+//   pass 1 (k_ntt_pass1): tile = 16 adjacent matrix columns i2 x all 256 i1; DFT over i1; multiply by
+//                         w_N^(i2*k1); write Y[k1][i2].
+//   pass 2 (k_ntt_pass2): tile = 16 matrix rows k1 x all 256 i2; DFT over i2; write X[k1 + 256*k2]
+//                         either in natural order or in bit-reversed (Merkle-leaf) order.
+// The 2N-point coset LDE is computed as two N-point coset NTTs (cosets g and g*w_2N); in bit-reversed
+// order they are the lower and upper half of the output, so no separate zero-padded 2N transform and
+// no bit-reversal pass exist.  Global accesses are 128-byte segments (16 lanes x 8 B) or 16-byte
+// vectors; twiddle / coset tables have the same access pattern as the data and stay L2-resident.
+#include "gl_dev.h"
+#include "ntt.h"
+
+// ---- radix-16 DFT in registers --------------------------------------------------------------------------
+// x*w16^e with w16 = 2^12 (forward) or 2^-12 (inverse); e in [0,8).
+template <bool INV, int E>
+__device__ __forceinline__ u64 mul_w16(u64 x) {
+  if constexpr (E == 0) return x;
+  else if constexpr (!INV) return gl_mul_2exp<12 * E>(x);
+  else return gl_mul_2exp<192 - 12 * E>(x);
+}
+template <bool INV, int SPAN, int G, int J>
+__device__ __forceinline__ void bfly16(u64* x) {
+  u64 a = x[G + J], b = x[G + J + SPAN];
+  x[G + J] = gl_add(a, b);
+  x[G + J + SPAN] = mul_w16<INV, J * (8 / SPAN)>(gl_sub(a, b));
+}
+// DIF network: natural-order input, output X[k] ends up in x[bitrev4(k)].
+template <bool INV>
+__device__ __forceinline__ void dft16(u64* x) {
+#define BF(SPAN, G, J) bfly16<INV, SPAN, G, J>(x)
+  BF(8, 0, 0); BF(8, 0, 1); BF(8, 0, 2); BF(8, 0, 3); BF(8, 0, 4); BF(8, 0, 5); BF(8, 0, 6); BF(8, 0, 7);
+  BF(4, 0, 0); BF(4, 0, 1); BF(4, 0, 2); BF(4, 0, 3); BF(4, 8, 0); BF(4, 8, 1); BF(4, 8, 2); BF(4, 8, 3);
+  BF(2, 0, 0); BF(2, 0, 1); BF(2, 4, 0); BF(2, 4, 1); BF(2, 8, 0); BF(2, 8, 1); BF(2, 12, 0); BF(2, 12, 1);
+  BF(1, 0, 0); BF(1, 2, 0); BF(1, 4, 0); BF(1, 6, 0); BF(1, 8, 0); BF(1, 10, 0); BF(1, 12, 0); BF(1, 14, 0);
+#undef BF
+}
+__device__ __forceinline__ constexpr int br4(int x) { return ((x & 1) << 3) | ((x & 2) << 1) | ((x & 4) >> 1) | ((x & 8) >> 3); }
+
+// 16 independent 256-point DFTs per 256-thread workgroup.  On entry thread (d, g) holds
+// x[m] = in_d[g + 16 m]; on exit thread (d, ka) holds x[br4(kb)] = X_d[ka + 16 kb].
+// The LDS transpose uses a padded image so that the write and the transposed read are both
+// bank-conflict free; MODE selects the lane layouts:
+//   0: lanes d-fast before and after (d = t&15)            slot = ka*272 + g*16 + d
+//   1: lanes g-fast before and after (g/ka = t&15)          slot = ka*257 + d*16 + g
+//   2: lanes g-fast before, d-fast after (re-maps d, ka)    slot = ka*272 + d*17 + g
+static constexpr int LDS_TILE_WORDS = 16 * 272;
+template <int MODE>
+__device__ __forceinline__ int lds_slot(int ka, int g, int d) {
+  return MODE == 0 ? ka * 272 + g * 16 + d : MODE == 1 ? ka * 257 + d * 16 + g : ka * 272 + d * 17 + g;
+}
+template <bool INV, int MODE>
+__device__ __forceinline__ void dft256_tile(u64* x, u64* lds, const u64* __restrict__ tw256, int& d, int& g) {
+  dft16<INV>(x);
+  // inner twiddle w_256^(g*ka), then transpose (g <-> ka) through LDS
+#pragma unroll
+  for (int ka = 0; ka < 16; ka++) {
+    u64 v = x[br4(ka)];
+    if (ka != 0) v = gl_mul(v, tw256[g * ka]);
+    lds[lds_slot<MODE>(ka, g, d)] = v;
+  }
+  __syncthreads();
+  if (MODE == 2) {
+    d = threadIdx.x & 15;
+    g = threadIdx.x >> 4;
+  }
+  const int ka2 = g;  // the thread now owns (d, ka = g)
+#pragma unroll
+  for (int gg = 0; gg < 16; gg++) x[gg] = lds[lds_slot<MODE>(ka2, gg, d)];
+  dft16<INV>(x);
+}
+
+// ---- pass 1 ---------------------------------------------------------------------------------------------------
+// grid = (16 tiles, ncols); block = 256.  in/out column strides in elements.
+template <bool INV>
+__global__ __launch_bounds__(256) void k_ntt_pass1(const u64* __restrict__ in, size_t in_stride, u64* __restrict__ out,
+                                                   size_t out_stride, const u64* __restrict__ pre,
+                                                   const u64* __restrict__ twmat, const u64* __restrict__ tw256) {
+  __shared__ u64 lds[LDS_TILE_WORDS];
+  const int t = threadIdx.x;
+  int d = t & 15, g = t >> 4;
+  const int i2 = blockIdx.x * 16 + d;
+  const u64* col = in + (size_t)blockIdx.y * in_stride;
+  u64 x[16];
+#pragma unroll
+  for (int m = 0; m < 16; m++) x[m] = col[(g + 16 * m) * 256 + i2];
+  if (pre) {
+#pragma unroll
+    for (int m = 0; m < 16; m++) x[m] = gl_mul(x[m], pre[(g + 16 * m) * 256 + i2]);
+  }
+  dft256_tile<INV, 0>(x, lds, tw256, d, g);
+  u64* ocol = out + (size_t)blockIdx.y * out_stride;
+  const int ka = g;
+#pragma unroll
+  for (int kb = 0; kb < 16; kb++) {
+    int k1 = ka + 16 * kb;
+    u64 v = x[br4(kb)];
+    v = gl_mul(v, twmat[k1 * 256 + i2]);
+    ocol[k1 * 256 + i2] = v;
+  }
+}
+
+// ---- pass 2 ---------------------------------------------------------------------------------------------------
+// grid = (16 tiles, ncols); block = 256.  Tile b handles rows k1 = b + 16*d (d = 0..15), so that in
+// bit-reversed output order the 16 rows br8(k1) = br4(b)*16 + br4(d) form one contiguous 32 KB region.
+// post: optional per-output-index (natural k) scale table; post_scalar multiplies everything (1/N).
+template <bool INV, bool OUT_BITREV>
+__global__ __launch_bounds__(256) void k_ntt_pass2(const u64* __restrict__ in, size_t in_stride, u64* __restrict__ out,
+                                                   size_t out_stride, const u64* __restrict__ post, u64 post_scalar,
+                                                   const u64* __restrict__ tw256) {
+  __shared__ u64 lds[LDS_TILE_WORDS];
+  const int t = threadIdx.x;
+  int g = t & 15, d = t >> 4;
+  // bit-reversed output: rows k1 = b + 16 d (their images br8(k1) are 16 consecutive output rows);
+  // natural output: rows k1 = 16 b + d (consecutive, so that stores along d are contiguous)
+  const int k1_load = OUT_BITREV ? blockIdx.x + 16 * d : blockIdx.x * 16 + d;
+  const u64* col = in + (size_t)blockIdx.y * in_stride;
+  u64 x[16];
+#pragma unroll
+  for (int m = 0; m < 16; m++) x[m] = col[k1_load * 256 + g + 16 * m];
+  dft256_tile<INV, OUT_BITREV ? 1 : 2>(x, lds, tw256, d, g);
+  const int k1 = OUT_BITREV ? blockIdx.x + 16 * d : blockIdx.x * 16 + d;
+  const int ka = g;
+  u64* ocol = out + (size_t)blockIdx.y * out_stride;
+  if (OUT_BITREV) {
+    // position = br8(k1)*256 + br8(k2), k2 = ka + 16*kb  ->  br4(ka)*16 + br4(kb): x[] is already in
+    // br4(kb) order, so the thread owns 16 consecutive words.
+    size_t base = (size_t)bitrev32(k1, 8) * 256 + br4(ka) * 16;
+#pragma unroll
+    for (int p = 0; p < 16; p += 2) {
+      u64 v0 = x[p], v1 = x[p + 1];
+      if (post_scalar != 1) {
+        v0 = gl_mul(v0, post_scalar);
+        v1 = gl_mul(v1, post_scalar);
+      }
+      ulonglong2 w;
+      w.x = v0;
+      w.y = v1;
+      *reinterpret_cast<ulonglong2*>(ocol + base + p) = w;
+    }
+  } else {
+#pragma unroll
+    for (int kb = 0; kb < 16; kb++) {
+      int k = k1 + 256 * (ka + 16 * kb);
+      u64 v = x[br4(kb)];
+      if (post) v = gl_mul(v, post[k]);
+      else if (post_scalar != 1) v = gl_mul(v, post_scalar);
+      ocol[k] = v;
+    }
+  }
+}
+
+// ---- host side ------------------------------------------------------------------------------------------------
+static void fill_pow_table(std::vector<u64>& t, u64 base, size_t n, u64 first = 1) {
+  t.resize(n);
+  u64 v = first;
+  for (size_t i = 0; i < n; i++) {
+    t[i] = v;
+    v = gl_mul(v, base);
+  }
+}
+
+int ntt_tables_init(NttTables* T) {
+  const size_t N = NTT_N;
+  std::vector<u64> h;
+  auto upload = [&](u64** dst, const std::vector<u64>& src) -> int {
+    if (hipMalloc((void**)dst, src.size() * 8) != hipSuccess) return -1;
+    if (hipMemcpy(*dst, src.data(), src.size() * 8, hipMemcpyHostToDevice) != hipSuccess) return -1;
+    return 0;
+  };
+  u64 wN = gl_root_of_unity(16), wNi = gl_inv(wN);
+  u64 w256 = gl_root_of_unity(8), w256i = gl_inv(w256);
+  fill_pow_table(h, w256, 256);
+  if (upload(&T->tw256_fwd, h)) return -1;
+  fill_pow_table(h, w256i, 256);
+  if (upload(&T->tw256_inv, h)) return -1;
+  // twmat[k1*256 + i2] = w_N^(i2*k1)
+  for (int inv = 0; inv < 2; inv++) {
+    u64 w = inv ? wNi : wN;
+    h.resize(N);
+    u64 wk = 1;  // w^k1
+    for (int k1 = 0; k1 < 256; k1++) {
+      u64 v = 1;
+      for (int i2 = 0; i2 < 256; i2++) {
+        h[k1 * 256 + i2] = v;
+        v = gl_mul(v, wk);
+      }
+      wk = gl_mul(wk, w);
+    }
+    if (upload(inv ? &T->twmat_inv : &T->twmat_fwd, h)) return -1;
+  }
+  // coset power tables: shift_h^i, shift_0 = g, shift_1 = g * w_2N
+  u64 w2N = gl_root_of_unity(17);
+  u64 shifts[2] = {GL_GEN, gl_mul(GL_GEN, w2N)};
+  u64 ninv = gl_inv((u64)N);
+  for (int hh = 0; hh < 2; hh++) {
+    fill_pow_table(h, shifts[hh], N);
+    if (upload(&T->coset_pow[hh], h)) return -1;
+    fill_pow_table(h, gl_inv(shifts[hh]), N, ninv);  // (1/N) * shift^-k
+    if (upload(&T->coset_inv_pow[hh], h)) return -1;
+  }
+  T->n_inv = ninv;
+  return 0;
+}
+
+void ntt_tables_free(NttTables* T) {
+  hipFree(T->tw256_fwd);
+  hipFree(T->tw256_inv);
+  hipFree(T->twmat_fwd);
+  hipFree(T->twmat_inv);
+  for (int h = 0; h < 2; h++) {
+    hipFree(T->coset_pow[h]);
+    hipFree(T->coset_inv_pow[h]);
+  }
+}
+
+// values[C][N] (natural) -> coefficients[C][N] (natural); in place allowed (uses tmp[C][N]).
+void ntt_inverse(const NttTables* T, const u64* values, u64* coeffs, u64* tmp, int ncols, hipStream_t s) {
+  dim3 grid(16, ncols), block(256);
+  k_ntt_pass1<true><<<grid, block, 0, s>>>(values, NTT_N, tmp, NTT_N, nullptr, T->twmat_inv, T->tw256_inv);
+  k_ntt_pass2<true, false><<<grid, block, 0, s>>>(tmp, NTT_N, coeffs, NTT_N, nullptr, T->n_inv, T->tw256_inv);
+}
+// coset iNTT of values given on coset `h` (natural order) -> coefficients (natural)
+void ntt_coset_inverse(const NttTables* T, int h, const u64* values, u64* coeffs, u64* tmp, int ncols, hipStream_t s) {
+  dim3 grid(16, ncols), block(256);
+  k_ntt_pass1<true><<<grid, block, 0, s>>>(values, NTT_N, tmp, NTT_N, nullptr, T->twmat_inv, T->tw256_inv);
+  k_ntt_pass2<true, false><<<grid, block, 0, s>>>(tmp, NTT_N, coeffs, NTT_N, T->coset_inv_pow[h], 1, T->tw256_inv);
+}
+// coefficients[C][N] -> lde[C][2N] in bit-reversed order (both cosets); tmp[C][N].
+void ntt_lde(const NttTables* T, const u64* coeffs, u64* lde, u64* tmp, int ncols, hipStream_t s) {
+  dim3 grid(16, ncols), block(256);
+  for (int h = 0; h < 2; h++) {
+    k_ntt_pass1<false><<<grid, block, 0, s>>>(coeffs, NTT_N, tmp, NTT_N, T->coset_pow[h], T->twmat_fwd, T->tw256_fwd);
+    k_ntt_pass2<false, true><<<grid, block, 0, s>>>(tmp, NTT_N, lde + (size_t)h * NTT_N, 2 * NTT_N, nullptr, 1, T->tw256_fwd);
+  }
+}
+// forward coset NTT on coset h, natural output (used for small FRI-side transforms and tests)
+void ntt_coset_forward_natural(const NttTables* T, int h, const u64* coeffs, u64* values, u64* tmp, int ncols, hipStream_t s) {
+  dim3 grid(16, ncols), block(256);
+  k_ntt_pass1<false><<<grid, block, 0, s>>>(coeffs, NTT_N, tmp, NTT_N, T->coset_pow[h], T->twmat_fwd, T->tw256_fwd);
+  k_ntt_pass2<false, false><<<grid, block, 0, s>>>(tmp, NTT_N, values, NTT_N, nullptr, 1, T->tw256_fwd);
+}

@@ -1,0 +1,81 @@
+// Poseidon-Goldilocks permutation (width 12, 4+22+4 rounds, x^7) and the plonky2 hashing conventions
+// hash_no_pad / hash_or_noop / two_to_one (PoseidonHash of PoseidonGoldilocksConfig, the config the
+// reference proves with: src/starks/curves/g1/scalar_mul_stark.rs:549, generators/g1/stark_proof.rs:152).
+// Round constants: tools/derive_poseidon_constants.py (ChaCha8 seed-0 derivation, KAT-checked).
+#pragma once
+#include "gl_dev.h"
+
+static const u64 POSEIDON_RC_HOST[360] = {
+#include "poseidon_constants.inc"
+};
+static __constant__ u64 POSEIDON_RC_DEV[360] = {
+#include "poseidon_constants.inc"
+};
+
+GL_HD u64 poseidon_rc(int i) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return POSEIDON_RC_DEV[i];
+#else
+  return POSEIDON_RC_HOST[i];
+#endif
+}
+
+GL_HD u64 poseidon_sbox(u64 x) {
+  u64 x2 = gl_sqr(x), x4 = gl_sqr(x2), x3 = gl_mul(x2, x);
+  return gl_mul(x3, x4);
+}
+
+// MDS: out[r] = sum_i s[(i+r)%12]*C[i] + (r==0)*8*s[0], C = {17,15,41,16,2,28,13,13,39,18,34,20}.
+// Lanes are split in 32-bit halves so that the small-constant products accumulate without carries
+// (each half-sum < 2^42); one 128-bit reduction per output lane.
+GL_HD void poseidon_mds(u64 s[12]) {
+  const u32 C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+  u64 lo[12], hi[12], out[12];
+#pragma unroll
+  for (int i = 0; i < 12; i++) {
+    lo[i] = s[i] & GL_EPS;
+    hi[i] = s[i] >> 32;
+  }
+#pragma unroll
+  for (int r = 0; r < 12; r++) {
+    u64 al = 0, ah = 0;
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+      al += lo[(i + r) % 12] * C[i];
+      ah += hi[(i + r) % 12] * C[i];
+    }
+    if (r == 0) {
+      al += lo[0] * 8;
+      ah += hi[0] * 8;
+    }
+    // value = al + ah*2^32 (< 2^75): lo64 = al + (ah<<32), hi = (ah>>32) + carry
+    u64 l = al + (ah << 32);
+    u64 h = (ah >> 32) + (l < al ? 1 : 0);
+    out[r] = gl_reduce128(l, h);
+  }
+#pragma unroll
+  for (int i = 0; i < 12; i++) s[i] = out[i];
+}
+
+GL_HD void poseidon_permute(u64 s[12]) {
+  for (int rnd = 0; rnd < 30; rnd++) {
+#pragma unroll
+    for (int i = 0; i < 12; i++) s[i] = gl_add(s[i], poseidon_rc(12 * rnd + i));
+    if (rnd < 4 || rnd >= 26) {
+#pragma unroll
+      for (int i = 0; i < 12; i++) s[i] = poseidon_sbox(s[i]);
+    } else {
+      s[0] = poseidon_sbox(s[0]);
+    }
+    poseidon_mds(s);
+  }
+}
+
+GL_HD void poseidon_two_to_one(const u64 l[4], const u64 r[4], u64 out[4]) {
+  u64 s[12] = {l[0], l[1], l[2], l[3], r[0], r[1], r[2], r[3], 0, 0, 0, 0};
+  poseidon_permute(s);
+  out[0] = s[0];
+  out[1] = s[1];
+  out[2] = s[2];
+  out[3] = s[3];
+}

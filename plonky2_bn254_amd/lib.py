@@ -1,0 +1,174 @@
+"""ctypes binding of libbn254stark.so (include/bn254_stark.h).  No CPU fallback: if the HIP library is
+missing or a call fails, an exception is raised."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libbn254stark.so")
+
+U64P = C.POINTER(C.c_uint64)
+
+
+class LibraryMissing(RuntimeError):
+    pass
+
+
+class Params(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in (
+        "struct_size", "security_bits", "num_challenges", "rate_bits", "cap_height", "pow_bits",
+        "arity_bits", "final_poly_bits", "num_queries", "min_rows_log2")]
+
+
+_lib = None
+
+
+def load_library():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise LibraryMissing(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(there is no CPU fallback for the proving path)")
+    lib = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    lib.bn254s_abi_version.restype = C.c_int
+    lib.bn254s_params_default.argtypes = [C.POINTER(Params)]
+    lib.bn254s_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
+    lib.bn254s_ctx_destroy.argtypes = [vp]
+    lib.bn254s_last_error.argtypes = [vp]
+    lib.bn254s_last_error.restype = C.c_char_p
+    for name in ("bn254s_prove_g1", "bn254s_prove_g2", "bn254s_prove_fq_exp"):
+        getattr(lib, name).argtypes = [vp, C.POINTER(Params), vp, vp, vp, C.c_size_t, C.POINTER(vp)]
+    lib.bn254s_prove_g1_batch.argtypes = [vp, C.POINTER(Params), vp, vp, vp, C.c_size_t, C.c_size_t, C.POINTER(vp)]
+    lib.bn254s_proof_words.argtypes = [vp, C.POINTER(U64P), C.POINTER(C.c_size_t)]
+    lib.bn254s_proof_outputs.argtypes = [vp, C.POINTER(U64P), C.POINTER(C.c_size_t)]
+    lib.bn254s_proof_degree_bits.argtypes = [vp]
+    lib.bn254s_proof_stage_ms.argtypes = [vp, C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.c_size_t)]
+    lib.bn254s_stage_name.argtypes = [C.c_size_t]
+    lib.bn254s_stage_name.restype = C.c_char_p
+    lib.bn254s_proof_free.argtypes = [vp]
+    lib.bn254s_commit_values.argtypes = [vp, vp, C.c_size_t, vp, vp, vp]
+    lib.bn254s_bench_ntt.argtypes = [vp, C.c_size_t, C.c_int, C.POINTER(C.c_float)]
+    lib.bn254s_poseidon_permute.argtypes = [vp, vp, C.c_size_t]
+    lib.bn254s_g1_generate_trace.argtypes = [vp, vp, vp, vp, C.c_size_t, C.c_uint32, vp, vp]
+    _lib = lib
+    return lib
+
+
+def default_params() -> Params:
+    p = Params()
+    load_library().bn254s_params_default(C.byref(p))
+    return p
+
+
+def _ptr(a: Optional[np.ndarray]):
+    if a is None:
+        return None
+    assert a.dtype == np.uint64 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Proof:
+    """Owns a bn254s_proof*; `words` is the canonical u64 layout documented in bn254_stark.h."""
+
+    def __init__(self, lib, handle):
+        self._lib, self._h = lib, handle
+        data, n = U64P(), C.c_size_t()
+        lib.bn254s_proof_words(handle, C.byref(data), C.byref(n))
+        self.words = np.ctypeslib.as_array(data, shape=(n.value,)).copy()
+        lib.bn254s_proof_outputs(handle, C.byref(data), C.byref(n))
+        self.outputs = np.ctypeslib.as_array(data, shape=(n.value,)).copy() if n.value else np.zeros(0, np.uint64)
+        self.degree_bits = lib.bn254s_proof_degree_bits(handle)
+        ms, k = C.POINTER(C.c_float)(), C.c_size_t()
+        lib.bn254s_proof_stage_ms(handle, C.byref(ms), C.byref(k))
+        self.stage_ms = {lib.bn254s_stage_name(i).decode(): float(ms[i]) for i in range(k.value)}
+
+    def close(self):
+        if self._h:
+            self._lib.bn254s_proof_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+
+class Context:
+    """One context per GPU (bn254s_ctx)."""
+
+    def __init__(self, device: int = 0):
+        self._h = None
+        self._lib = load_library()
+        h = C.c_void_p()
+        rc = self._lib.bn254s_ctx_create(device, C.byref(h))
+        if rc != 0:
+            raise RuntimeError(f"bn254s_ctx_create(device={device}) failed with {rc} (is a GPU visible?)")
+        self._h = h
+        self.device = device
+
+    def close(self):
+        if self._h:
+            self._lib.bn254s_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise RuntimeError(f"{what} failed with {rc}: {self._lib.bn254s_last_error(self._h).decode()}")
+
+    # ---- proving (mirrors run_once of the reference generators) ----
+    def prove_g1(self, scalars, x, offset, params: Optional[Params] = None) -> Proof:
+        params = params or default_params()
+        n = scalars.shape[0]
+        out = C.c_void_p()
+        self._check(self._lib.bn254s_prove_g1(self._h, C.byref(params), _ptr(scalars), _ptr(x), _ptr(offset), n,
+                                              C.byref(out)), "bn254s_prove_g1")
+        return Proof(self._lib, out)
+
+    def prove_g1_batch(self, scalars, x, offset, per_proof=128, params: Optional[Params] = None, keep=True):
+        params = params or default_params()
+        n = scalars.shape[0]
+        k = (n + per_proof - 1) // per_proof
+        outs = (C.c_void_p * k)()
+        self._check(self._lib.bn254s_prove_g1_batch(self._h, C.byref(params), _ptr(scalars), _ptr(x), _ptr(offset), n,
+                                                    per_proof, outs), "bn254s_prove_g1_batch")
+        proofs = [Proof(self._lib, C.c_void_p(outs[i])) for i in range(k)]
+        return proofs
+
+    # ---- kernel-level entry points ----
+    def commit_values(self, values: np.ndarray, want_coeffs=True, want_lde=True):
+        ncols, n = values.shape
+        assert n == 65536
+        coeffs = np.zeros((ncols, n), np.uint64) if want_coeffs else None
+        lde = np.zeros((ncols, 2 * n), np.uint64) if want_lde else None
+        cap = np.zeros((16, 4), np.uint64)
+        self._check(self._lib.bn254s_commit_values(self._h, _ptr(values), ncols, _ptr(coeffs), _ptr(lde), _ptr(cap)),
+                    "bn254s_commit_values")
+        return coeffs, lde, cap
+
+    def bench_ntt(self, ncols: int, iters: int = 10) -> float:
+        ms = C.c_float()
+        self._check(self._lib.bn254s_bench_ntt(self._h, ncols, iters, C.byref(ms)), "bn254s_bench_ntt")
+        return ms.value
+
+    def poseidon_permute(self, states: np.ndarray) -> np.ndarray:
+        st = np.ascontiguousarray(states, dtype=np.uint64).copy()
+        self._check(self._lib.bn254s_poseidon_permute(self._h, _ptr(st), st.shape[0]), "bn254s_poseidon_permute")
+        return st
+
+    def g1_generate_trace(self, scalars, x, offset, min_rows_log2=16, width=781):
+        n = scalars.shape[0]
+        rows = max(1 << min_rows_log2, 512 * n)
+        rows = 1 << (rows - 1).bit_length()
+        trace = np.zeros((width, rows), np.uint64)
+        outs = np.zeros((n, 8), np.uint64)
+        self._check(self._lib.bn254s_g1_generate_trace(self._h, _ptr(scalars), _ptr(x), _ptr(offset), n, min_rows_log2,
+                                                       _ptr(trace), _ptr(outs)), "bn254s_g1_generate_trace")
+        return trace, outs
