@@ -50,7 +50,8 @@ enum {
   BN254S_E_OOM = -3,
   BN254S_E_INVALID_POINT = -4,  /* a + (-a) met during the double-and-add chain (generate_g1_add, add.rs:49-51) */
   BN254S_E_UNSUPPORTED = -5,    /* shape not implemented by this build */
-  BN254S_E_TRANSCRIPT = -6      /* opening point inside the subgroup (starky "Opening point is in the subgroup") */
+  BN254S_E_TRANSCRIPT = -6,     /* opening point inside the subgroup (starky "Opening point is in the subgroup") */
+  BN254S_E_INTERNAL = -7        /* a device-side self check failed (the reference's assert!s in modulus_zero.rs:82,99-103) */
 };
 
 typedef struct bn254s_ctx bn254s_ctx;

@@ -176,6 +176,7 @@ static inline std::vector<std::vector<u64>> generate_trace(const std::vector<Inp
     for (size_t i = 0; i < num_rows; i++) {
       u64 x = trace[c][i];
       if (x >= range_max) throw std::runtime_error("range check value out of range");
+      if (x >= num_rows) throw std::runtime_error("index out of bounds: fewer than 2^16 rows (reference rows[x][FREQ_COL], scalar_mul_stark.rs:84)");
       freq[x] += 1;
     }
   return trace;

@@ -1,0 +1,454 @@
+// G1 scalar-multiplication STARK: trace generation on the GPU (K-trace-A / K-trace-B of DESIGN.md).
+//
+// Replaces the single-threaded CPU loops of the reference:
+//   G1ScalarMulStark::generate_trace / generate_one_set / generate_first_row / generate_transition
+//     (src/starks/curves/g1/scalar_mul_stark.rs:55-213),
+//   generate_g1_add (src/starks/curves/g1/add.rs:52-122),
+//   generate_is_modulus_zero (src/starks/modular/is_modulus_zero.rs:36-66),
+//   generate_modulus_zero (src/starks/modular/modulus_zero.rs:77-123, incl. pol_remove_root_2exp),
+//   generate_round_flags (src/starks/common/round_flags.rs:21-44), generate_range_checks (:71-87).
+// Column layout: src/starks/curves/g1/scalar_mul_view.rs:34-49 (see trace_g1.h).
+//
+// Phase A (sequential per instance, no inversions): double-and-add chain in Jacobian coordinates, every
+// intermediate point (offset, C_k = S_{k-1} + D_k, D_k = 2^k x) is stored.  Phase A' : all Z are inverted
+// with Montgomery's batch trick.  Phase B (one thread per trace row): affine a, b, c, lambda and the limb /
+// quotient / carry witnesses; the exact division by p is a multiplication by p^-1 mod 2^288.
+// The trace is written column-major (trace[c*N + row]), so consecutive lanes write consecutive words.
+#include "fq_dev.h"
+#include "trace_g1.h"
+
+// ---- SoA vectors of Fq elements: element e, limb l at base[l*count + e] ---------------------------------
+__device__ __forceinline__ fq ld_fq(const u64* base, size_t count, size_t e) {
+  fq r;
+#pragma unroll
+  for (int l = 0; l < 4; l++) r.l[l] = base[l * count + e];
+  return r;
+}
+__device__ __forceinline__ void st_fq(u64* base, size_t count, size_t e, const fq& v) {
+#pragma unroll
+  for (int l = 0; l < 4; l++) base[l * count + e] = v.l[l];
+}
+
+// Point table per instance: 0 = offset, 1+k = C_k (k<256), 257+k = D_k (k<=256)
+static constexpr int NPTS = 514;
+
+// ---- phase A: the chain -----------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_g1_chain(const u64* __restrict__ scalars, const u64* __restrict__ xs,
+                                                 const u64* __restrict__ offs, int n, u64* __restrict__ px,
+                                                 u64* __restrict__ py, u64* __restrict__ pz, int* __restrict__ err) {
+  int inst = blockIdx.x * blockDim.x + threadIdx.x;
+  if (inst >= n) return;
+  size_t cnt = (size_t)NPTS * n;
+  u64 s[4];
+  for (int i = 0; i < 4; i++) s[i] = scalars[4 * inst + i];
+  g1j S, D;
+  D.x = fq_from_canonical(xs + 8 * inst);
+  D.y = fq_from_canonical(xs + 8 * inst + 4);
+  D.z = fq_one();
+  S.x = fq_from_canonical(offs + 8 * inst);
+  S.y = fq_from_canonical(offs + 8 * inst + 4);
+  S.z = fq_one();
+  auto store = [&](int pt, const g1j& p) {
+    size_t e = (size_t)pt * n + inst;
+    st_fq(px, cnt, e, p.x);
+    st_fq(py, cnt, e, p.y);
+    st_fq(pz, cnt, e, p.z);
+  };
+  store(0, S);
+  for (int k = 0; k < 256; k++) {
+    g1j C;
+    int rc = g1_add(S, D, C);
+    if (rc == 2) atomicCAS(err, 0, BN254S_E_INVALID_POINT);
+    store(1 + k, C);
+    store(257 + k, D);
+    if ((s[k >> 6] >> (k & 63)) & 1) S = C;
+    D = g1_double(D);
+  }
+  store(513, D);
+}
+
+// ---- batched field inversion ------------------------------------------------------------------------------
+// out[e] = in[e]^-1 (0 -> 0); each thread owns CH elements strided by the grid size.
+template <int CH>
+__global__ __launch_bounds__(64) void k_fq_batch_inv(const u64* __restrict__ in, u64* __restrict__ out, size_t count) {
+  size_t T = (size_t)gridDim.x * blockDim.x, tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  fq v[CH], pre[CH];
+  fq acc = fq_one();
+#pragma unroll
+  for (int j = 0; j < CH; j++) {
+    size_t e = tid + j * T;
+    v[j] = e < count ? ld_fq(in, count, e) : fq_zero();
+    pre[j] = acc;
+    if (!fq_is_zero(v[j])) acc = fq_mul(acc, v[j]);
+  }
+  fq inv = fq_inv(acc);
+#pragma unroll
+  for (int j = CH - 1; j >= 0; j--) {
+    size_t e = tid + j * T;
+    if (e < count) {
+      if (fq_is_zero(v[j])) {
+        st_fq(out, count, e, fq_zero());
+      } else {
+        st_fq(out, count, e, fq_mul(inv, pre[j]));
+        inv = fq_mul(inv, v[j]);
+      }
+    }
+  }
+}
+
+// ---- phase B helpers ------------------------------------------------------------------------------------------
+struct AffPt {
+  fq x, y;
+};
+__device__ __forceinline__ AffPt affine_pt(const u64* px, const u64* py, const u64* zi, size_t cnt, size_t e) {
+  fq z = ld_fq(zi, cnt, e);
+  fq z2 = fq_sqr(z);
+  AffPt r;
+  r.x = fq_mul(ld_fq(px, cnt, e), z2);
+  r.y = fq_mul(fq_mul(ld_fq(py, cnt, e), z2), z);
+  return r;
+}
+// index of the highest set bit of s below position k, or -1
+__device__ __forceinline__ int last_set_below(const u64 s[4], int k) {
+  for (int w = 3; w >= 0; w--) {
+    int lo = w * 64;
+    if (k <= lo) continue;
+    u64 m = s[w];
+    if (k < lo + 64) m &= (1ULL << (k - lo)) - 1;
+    if (m) return lo + 63 - __clzll((long long)m);
+  }
+  return -1;
+}
+// point index of the running sum after step k-1 (S_{k-1}); k = 0 -> offset
+__device__ __forceinline__ int sum_point(const u64 s[4], int k) {
+  int j = last_set_below(s, k);
+  return j < 0 ? 0 : 1 + j;
+}
+
+// denominators: add row: b.x - a.x (or 2 a.y when the x coincide); doubling row: 2 a.y
+__global__ __launch_bounds__(64) void k_g1_row_den(const u64* __restrict__ scalars, int n, const u64* __restrict__ px,
+                                                   const u64* __restrict__ py, const u64* __restrict__ zi,
+                                                   u64* __restrict__ den) {
+  size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t nrows = (size_t)n * 512;
+  if (r >= nrows) return;
+  int inst = (int)(r >> 9), row = (int)(r & 511), k = row >> 1;
+  size_t cnt = (size_t)NPTS * n;
+  u64 s[4];
+  for (int i = 0; i < 4; i++) s[i] = scalars[4 * inst + i];
+  fq d;
+  if ((row & 1) == 0) {
+    AffPt a = affine_pt(px, py, zi, cnt, (size_t)sum_point(s, k) * n + inst);
+    AffPt b = affine_pt(px, py, zi, cnt, (size_t)(257 + k) * n + inst);
+    d = fq_sub(b.x, a.x);
+    if (fq_is_zero(d)) d = fq_dbl(a.y);
+  } else {
+    AffPt a = affine_pt(px, py, zi, cnt, (size_t)(257 + k) * n + inst);
+    d = fq_dbl(a.y);
+  }
+  st_fq(den, nrows, r, d);
+}
+
+__device__ __forceinline__ void fq_to_limbs(const fq& mont, int limbs[16]) {
+  fq c = fq_to_canonical(mont);
+#pragma unroll
+  for (int i = 0; i < 16; i++) limbs[i] = (int)((c.l[i >> 2] >> (16 * (i & 3))) & 0xFFFF);
+}
+
+__device__ static constexpr int MOD_LIMBS[16] = {64839, 55420, 35862, 15392, 51853, 26737, 27281, 38785,
+                                                  22621, 33153, 17846, 47184, 41001, 57649, 20082, 12388};
+// p^-1 mod 2^288, 32-bit words
+__device__ static constexpr u32 PINV288[9] = {0x1b799c77u, 0x782df87du, 0xe1359536u, 0x6121829au, 0xe7cc257fu,
+                                               0x2750342fu, 0x6e777394u, 0x0a85dd48u, 0x5b52d390u};
+
+// generate_modulus_zero (modulus_zero.rs:77-123): in = 31 signed limb coefficients of a multiple of p.
+// Writes the 80 witness values to columns col0.. of `row` (trace column-major, N rows).
+__device__ __noinline__ void gen_modulus_zero(const long long* in, u64* __restrict__ trace, size_t N, size_t row, int col0,
+                                              int* err) {
+  // low 288 bits of V = sum in[i] 2^(16 i), two's complement
+  u32 v[9];
+  long long carry = 0;
+#pragma unroll
+  for (int w = 0; w < 9; w++) {
+    long long t = carry + in[2 * w] + (in[2 * w + 1] << 16);
+    v[w] = (u32)t;
+    carry = t >> 32;
+  }
+  // q = V * p^-1 mod 2^288 (exact quotient, two's complement)
+  u32 q[9];
+  u128 acc = 0;
+#pragma unroll
+  for (int k = 0; k < 9; k++) {
+#pragma unroll
+    for (int i = 0; i <= k; i++) acc += (u64)v[i] * PINV288[k - i];
+    q[k] = (u32)acc;
+    acc >>= 32;
+  }
+  bool neg = (q[8] >> 31) != 0;
+  bool nonzero = false;
+  if (neg) {  // |q| = -q
+    u64 c = 1;
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+      c += (u64)(~q[k]);
+      q[k] = (u32)c;
+      c >>= 32;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 9; k++) nonzero |= q[k] != 0;
+  int qabs[17];
+#pragma unroll
+  for (int i = 0; i < 17; i++) qabs[i] = (int)((q[i >> 1] >> (16 * (i & 1))) & 0xFFFF);
+  if ((q[8] >> 16) != 0) atomicCAS(err, 0, BN254S_E_INTERNAL);  // quotient wider than 17 limbs
+  // constr = in - quot(x) * m(x)
+  long long constr[32];
+#pragma unroll
+  for (int i = 0; i < 31; i++) constr[i] = in[i];
+  constr[31] = 0;
+  const int sgn = neg ? -1 : 1;
+#pragma unroll
+  for (int i = 0; i < 17; i++) {
+    long long qi = (long long)(sgn * qabs[i]);
+#pragma unroll
+    for (int j = 0; j < 16; j++) constr[i + j] -= qi * MOD_LIMBS[j];
+  }
+  u64* out = trace + (size_t)col0 * N + row;
+  out[0] = (!neg && nonzero) ? 1 : 0;
+#pragma unroll
+  for (int i = 0; i < 17; i++) out[(size_t)(1 + i) * N] = (u64)qabs[i];
+  // aux = constr / (x - 2^16) (pol_remove_root_2exp), shifted by 2^29, split in 16-bit halves
+  long long a = -(constr[0] >> 16);
+  bool bad = false;
+#pragma unroll
+  for (int d = 0; d < 31; d++) {
+    if (d > 0) a = (a - constr[d]) >> 16;
+    long long sh = a + (1LL << 29);
+    bad |= (sh < 0) | (sh > (1LL << 30));
+    out[(size_t)(18 + d) * N] = (u64)(sh & 0xFFFF);
+    out[(size_t)(49 + d) * N] = (u64)((sh >> 16) & 0xFFFF);
+  }
+  // exactness: the last carry must vanish, otherwise `in` was not a multiple of p
+  if (bad || a != constr[31]) atomicCAS(err, 0, BN254S_E_INTERNAL);
+}
+
+__device__ __forceinline__ void pol_mul16(const int* a, const int* b, long long* out /*31*/) {
+#pragma unroll
+  for (int i = 0; i < 31; i++) out[i] = 0;
+#pragma unroll
+  for (int i = 0; i < 16; i++)
+#pragma unroll
+    for (int j = 0; j < 16; j++) out[i + j] += (long long)a[i] * b[j];
+}
+
+// Goldilocks inverses of counter and counter-511 for counter in [0,512): computed once per context.
+__global__ void k_round_flag_table(u64* tbl /* [2][512] */) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= 512) return;
+  tbl[c] = c == 0 ? 0 : gl_inv((u64)c);
+  u64 cp = gl_sub((u64)c, 511);
+  tbl[512 + c] = cp == 0 ? 0 : gl_inv(cp);
+}
+
+// ---- phase B: one thread per trace row ----------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_g1_rows(const u64* __restrict__ scalars, int n, const u64* __restrict__ px,
+                                                const u64* __restrict__ py, const u64* __restrict__ zi,
+                                                const u64* __restrict__ deninv, const u64* __restrict__ rf_tbl,
+                                                u64* __restrict__ trace, size_t N, int* __restrict__ err) {
+  size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t nrows = (size_t)n * 512;
+  if (r >= nrows) return;
+  const int inst = (int)(r >> 9), row = (int)(r & 511), k = row >> 1;
+  const bool adding = (row & 1) == 0;
+  const size_t cnt = (size_t)NPTS * n;
+  u64 s[4];
+  for (int i = 0; i < 4; i++) s[i] = scalars[4 * inst + i];
+  const bool bitk = (s[k >> 6] >> (k & 63)) & 1;
+
+  AffPt a, b, c, sum, dbl;
+  if (adding) {
+    a = affine_pt(px, py, zi, cnt, (size_t)sum_point(s, k) * n + inst);
+    b = affine_pt(px, py, zi, cnt, (size_t)(257 + k) * n + inst);
+    c = affine_pt(px, py, zi, cnt, (size_t)(1 + k) * n + inst);
+    dbl = b;
+    sum = bitk ? c : a;
+  } else {
+    a = affine_pt(px, py, zi, cnt, (size_t)(257 + k) * n + inst);
+    b = a;
+    c = affine_pt(px, py, zi, cnt, (size_t)(258 + k) * n + inst);
+    dbl = c;
+    sum = affine_pt(px, py, zi, cnt, (size_t)sum_point(s, k + 1) * n + inst);
+  }
+  const fq di = ld_fq(deninv, nrows, r);
+  const bool x_eq = fq_eq(a.x, b.x);
+  fq lambda, inv;
+  if (!x_eq) {
+    lambda = fq_mul(fq_sub(b.y, a.y), di);  // add.rs:66
+    inv = di;
+  } else {
+    fq xx = fq_sqr(a.x);
+    lambda = fq_mul(fq_add(fq_dbl(xx), xx), di);  // 3x^2 / 2y, add.rs:80
+    inv = fq_zero();
+  }
+
+  auto put = [&](int col, u64 v) { trace[(size_t)col * N + r] = v; };
+  int ax[16], ay[16], bx[16], by[16], cx[16], cy[16], lam[16], invl[16], t16[16];
+  fq_to_limbs(a.x, ax);
+  fq_to_limbs(a.y, ay);
+  fq_to_limbs(b.x, bx);
+  fq_to_limbs(b.y, by);
+  fq_to_limbs(c.x, cx);
+  fq_to_limbs(c.y, cy);
+  fq_to_limbs(lambda, lam);
+  fq_to_limbs(inv, invl);
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    put(G1_COL_A + i, ax[i]);
+    put(G1_COL_A + 16 + i, ay[i]);
+    put(G1_COL_B + i, bx[i]);
+    put(G1_COL_B + 16 + i, by[i]);
+    put(G1_COL_C + i, cx[i]);
+    put(G1_COL_C + 16 + i, cy[i]);
+    put(G1_COL_AUX + G1_AUX_LAMBDA + i, lam[i]);
+    put(G1_COL_AUX + G1_AUX_IS_X_EQ_AUX + i, invl[i]);
+  }
+  fq_to_limbs(dbl.x, t16);
+#pragma unroll
+  for (int i = 0; i < 16; i++) put(G1_COL_DOUBLE + i, t16[i]);
+  fq_to_limbs(dbl.y, t16);
+#pragma unroll
+  for (int i = 0; i < 16; i++) put(G1_COL_DOUBLE + 16 + i, t16[i]);
+  fq_to_limbs(sum.x, t16);
+#pragma unroll
+  for (int i = 0; i < 16; i++) put(G1_COL_SUM + i, t16[i]);
+  fq_to_limbs(sum.y, t16);
+#pragma unroll
+  for (int i = 0; i < 16; i++) put(G1_COL_SUM + 16 + i, t16[i]);
+
+  const u64 is_x_eq = x_eq ? 1 : 0;
+  put(G1_COL_AUX + G1_AUX_IS_X_EQ, is_x_eq);
+  put(G1_COL_AUX + G1_AUX_IS_X_EQ_FILTER, is_x_eq);
+
+  int dx[16];
+#pragma unroll
+  for (int i = 0; i < 16; i++) dx[i] = bx[i] - ax[i];
+  long long diff[31], tmp[31];
+  // is_modulus_zero witness: delta_x * inv - 1 + is_zero   (is_modulus_zero.rs:57-59)
+  pol_mul16(dx, invl, diff);
+  diff[0] += (long long)is_x_eq - 1;
+  gen_modulus_zero(diff, trace, N, r, G1_COL_AUX + G1_AUX_IS_X_EQ_AUX + 16, err);
+  // lambda witness
+  if (!x_eq) {
+    pol_mul16(lam, dx, diff);  // lambda*(b.x-a.x) - (b.y-a.y)
+#pragma unroll
+    for (int i = 0; i < 16; i++) diff[i] -= (long long)(by[i] - ay[i]);
+  } else {
+    pol_mul16(lam, ay, diff);  // 2*a.y*lambda - 3*a.x^2
+    pol_mul16(ax, ax, tmp);
+#pragma unroll
+    for (int i = 0; i < 31; i++) diff[i] = 2 * diff[i] - 3 * tmp[i];
+  }
+  gen_modulus_zero(diff, trace, N, r, G1_COL_AUX + G1_AUX_LAMBDA_AUX, err);
+  // x witness: lambda^2 - (a.x + b.x + c.x)
+  pol_mul16(lam, lam, diff);
+#pragma unroll
+  for (int i = 0; i < 16; i++) diff[i] -= (long long)(ax[i] + bx[i] + cx[i]);
+  gen_modulus_zero(diff, trace, N, r, G1_COL_AUX + G1_AUX_X_AUX, err);
+  // y witness: lambda*(c.x - a.x) + c.y + a.y
+#pragma unroll
+  for (int i = 0; i < 16; i++) t16[i] = cx[i] - ax[i];
+  pol_mul16(lam, t16, diff);
+#pragma unroll
+  for (int i = 0; i < 16; i++) diff[i] += (long long)(cy[i] + ay[i]);
+  gen_modulus_zero(diff, trace, N, r, G1_COL_AUX + G1_AUX_Y_AUX, err);
+
+  // bits rotated left by k (scalar_mul_stark.rs:163-167), flags and bookkeeping columns
+  for (int i = 0; i < 256; i++) {
+    int src = (i + k) & 255;
+    put(G1_COL_BITS + i, (s[src >> 6] >> (src & 63)) & 1);
+  }
+  put(G1_COL_FLAGS + 0, row == 0);
+  put(G1_COL_FLAGS + 1, row == 511);
+  put(G1_COL_FLAGS + 2, (u64)row);
+  put(G1_COL_FLAGS + 3, rf_tbl[row]);
+  put(G1_COL_FLAGS + 4, rf_tbl[512 + row]);
+  put(G1_COL_TIMESTAMP, (u64)inst);
+  put(G1_COL_IS_ADDING, adding ? 1 : 0);
+  put(G1_COL_IDNL, adding ? 0 : (row == 511 ? 0 : 1));
+  put(G1_COL_FILTER, 1);
+}
+
+// ---- range-check columns (generate_range_checks, scalar_mul_stark.rs:71-87) ----------------------------
+__global__ __launch_bounds__(256) void k_histogram(const u64* __restrict__ trace, size_t N, int col_begin, int col_end,
+                                                   u32* __restrict__ hist, int* __restrict__ err) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t total = (size_t)(col_end - col_begin) * N;
+  for (; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    u64 v = trace[(size_t)col_begin * N + i];
+    if (v >= 65536) {
+      atomicCAS(err, 0, BN254S_E_INTERNAL);
+      continue;
+    }
+    atomicAdd(&hist[v], 1u);
+  }
+}
+__global__ __launch_bounds__(256) void k_range_columns(u64* __restrict__ trace, size_t N, int freq_col, int range_col,
+                                                       const u32* __restrict__ hist) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  trace[(size_t)range_col * N + i] = i < 65536 ? i : 65535;
+  trace[(size_t)freq_col * N + i] = i < 65536 ? (u64)hist[i] : 0;
+}
+
+// ---- final outputs: s*x + offset = S_255 in canonical affine form ------------------------------------------
+__global__ void k_g1_outputs(const u64* __restrict__ scalars, int n, const u64* __restrict__ px, const u64* __restrict__ py,
+                             const u64* __restrict__ zi, u64* __restrict__ out8) {
+  int inst = blockIdx.x * blockDim.x + threadIdx.x;
+  if (inst >= n) return;
+  u64 s[4];
+  for (int i = 0; i < 4; i++) s[i] = scalars[4 * inst + i];
+  AffPt p = affine_pt(px, py, zi, (size_t)NPTS * n, (size_t)sum_point(s, 256) * n + inst);
+  fq x = fq_to_canonical(p.x), y = fq_to_canonical(p.y);
+  for (int i = 0; i < 4; i++) {
+    out8[8 * inst + i] = x.l[i];
+    out8[8 * inst + 4 + i] = y.l[i];
+  }
+}
+
+// ---- host driver ------------------------------------------------------------------------------------------------
+size_t g1_trace_scratch_words(size_t n) {
+  size_t cnt = (size_t)NPTS * n, nrows = n * 512;
+  return 4 * cnt * 4 /* px py pz zi */ + 2 * 4 * nrows /* den, deninv */ + 1024 /* rf table */ + 65536 / 2 /* hist */;
+}
+
+int g1_generate_trace_device(const u64* d_scalars, const u64* d_x, const u64* d_off, size_t n, u64* d_trace, size_t N,
+                             u64* d_scratch, u64* d_outputs, int* d_err, hipStream_t st) {
+  size_t cnt = (size_t)NPTS * n, nrows = n * 512;
+  u64* px = d_scratch;
+  u64* py = px + 4 * cnt;
+  u64* pz = py + 4 * cnt;
+  u64* zi = pz + 4 * cnt;
+  u64* den = zi + 4 * cnt;
+  u64* deninv = den + 4 * nrows;
+  u64* rf = deninv + 4 * nrows;
+  u32* hist = (u32*)(rf + 1024);
+  if (nrows < N) hipMemsetAsync(d_trace, 0, (size_t)G1_W * N * 8, st);
+  hipMemsetAsync(hist, 0, 65536 * 4, st);
+  k_round_flag_table<<<2, 256, 0, st>>>(rf);
+  k_g1_chain<<<(unsigned)((n + 63) / 64), 64, 0, st>>>(d_scalars, d_x, d_off, (int)n, px, py, pz, d_err);
+  const int CH = 8;
+  {
+    size_t threads = (cnt + CH - 1) / CH;
+    k_fq_batch_inv<CH><<<(unsigned)((threads + 63) / 64), 64, 0, st>>>(pz, zi, cnt);
+  }
+  k_g1_row_den<<<(unsigned)((nrows + 63) / 64), 64, 0, st>>>(d_scalars, (int)n, px, py, zi, den);
+  {
+    size_t threads = (nrows + CH - 1) / CH;
+    k_fq_batch_inv<CH><<<(unsigned)((threads + 63) / 64), 64, 0, st>>>(den, deninv, nrows);
+  }
+  k_g1_rows<<<(unsigned)((nrows + 63) / 64), 64, 0, st>>>(d_scalars, (int)n, px, py, zi, deninv, rf, d_trace, N, d_err);
+  k_histogram<<<2048, 256, 0, st>>>(d_trace, N, G1_RC_BEGIN, G1_RC_END, hist, d_err);
+  k_range_columns<<<(unsigned)((N + 255) / 256), 256, 0, st>>>(d_trace, N, G1_COL_FREQ, G1_COL_RANGE, hist);
+  if (d_outputs) k_g1_outputs<<<(unsigned)((n + 63) / 64), 64, 0, st>>>(d_scalars, (int)n, px, py, zi, d_outputs);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
