@@ -45,7 +45,14 @@ void bn254s_ctx_destroy(bn254s_ctx* c) {
   if (!c) return;
   hipSetDevice(c->device);
   hipStreamSynchronize(c->stream);
-  for (auto& kv : c->pool) hipFree(kv.second.first);
+  for (Slot* s : c->slots) {
+    hipStreamSynchronize(s->st);
+    s->mem.release();
+    if (s->pinned) hipHostFree(s->pinned);
+    hipStreamDestroy(s->st);
+    delete s;
+  }
+  c->release();
   ntt_tables_free(&c->ntt);
   hipStreamDestroy(c->stream);
   delete c;

@@ -4,19 +4,16 @@
 #include <vector>
 #include <map>
 #include <cstdio>
+#include <mutex>
 #include <hip/hip_runtime.h>
 #include "../../include/bn254_stark.h"
 #include "gl_dev.h"
 #include "ntt.h"
 
-struct bn254s_ctx {
-  int device = 0;
-  hipStream_t stream = nullptr;
-  NttTables ntt;
-  std::string err;
-  // pooled device buffers, keyed by name; grown on demand and kept for the life of the context
+// Named, grow-only device buffers (kept for the life of their owner).
+struct BufPool {
   std::map<std::string, std::pair<void*, size_t>> pool;
-
+  std::string err;
   void* buf(const std::string& name, size_t bytes) {
     auto it = pool.find(name);
     if (it != pool.end() && it->second.second >= bytes) return it->second.first;
@@ -33,6 +30,37 @@ struct bn254s_ctx {
     return p;
   }
   u64* words(const std::string& name, size_t n) { return (u64*)buf(name, n * 8); }
+  bool has(const std::string& name) const { return pool.find(name) != pool.end(); }
+  void release() {
+    for (auto& kv : pool) hipFree(kv.second.first);
+    pool.clear();
+  }
+};
+
+// A slot = stream + workspace of one proof in flight (bn254s_prove_g1_batch pipelines several).
+struct Slot {
+  hipStream_t st = nullptr;
+  BufPool mem;
+  void* pinned = nullptr;  // pinned host staging buffer
+  size_t pinned_bytes = 0;
+};
+
+struct bn254s_ctx : BufPool {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  NttTables ntt;
+  std::vector<Slot*> slots;
+  Slot* slot(size_t i) {
+    while (slots.size() <= i) {
+      Slot* s = new Slot();
+      if (hipStreamCreateWithFlags(&s->st, hipStreamNonBlocking) != hipSuccess) {
+        delete s;
+        return nullptr;
+      }
+      slots.push_back(s);
+    }
+    return slots[i];
+  }
 };
 
 #define HIP_TRY(ctx, call)                                                                  \

@@ -1,0 +1,36 @@
+// Host interface of the openings / FRI kernels (fri.hip).
+#pragma once
+#include "quotient_common.h"
+
+__host__ __device__ inline size_t merkle_level_offset_dev(int log_leaves, int level) {
+  // sum_{l<level} 2^(log_leaves-l) = 2^(log_leaves+1) - 2^(log_leaves-level+1)
+  return ((size_t)2 << log_leaves) - ((size_t)2 << (log_leaves - level));
+}
+
+// out[p*5 ..] = {P(zeta).c0,.c1, P(g zeta).c0,.c1, P(1)} for each of npolys coefficient vectors of length N
+void fri_openings(const u64* d_coeffs, size_t N, int npolys, gl2 zeta, gl2 zeta_next, u64* d_out, hipStream_t st);
+
+// d_out[2N][2]: sum_b alpha^(k_b) (F_b(x) - F_b(z_b)) / (x - z_b) on the LDE domain, bit-reversed order
+void fri_combine(const StarkShape& sh, const u64* d_tl, const u64* d_al, const u64* d_ql, const u64* d_apow, const u64* d_xs,
+                 gl2 zeta, gl2 zeta_next, gl2 r0, gl2 r1, gl2 r2, gl2 alpha, size_t M2, u64* d_out, hipStream_t st);
+
+void fri_fold(const u64* d_in, u64* d_out, unsigned log_m, u64 shift, gl2 beta, u64 inv16, hipStream_t st);
+
+void fri_pow_launch(const u64 state[12], int pos, u64 base, unsigned pow_bits, size_t count, unsigned long long* d_result,
+                    hipStream_t st);
+
+static constexpr int FRI_MAX_LAYERS = 8;
+struct QueryGatherArgs {
+  const u64* lde[3];
+  const u64* tree[3];
+  int width[3];
+  const u64* layer_vals[FRI_MAX_LAYERS];
+  const u64* layer_tree[FRI_MAX_LAYERS];
+  int n_layers;
+  int log_m2, cap_height;
+  size_t M2;
+  const u32* indices;
+  u64* out;
+  size_t words_per_query;
+};
+void fri_gather_queries(const QueryGatherArgs& A, int n_queries, hipStream_t st);

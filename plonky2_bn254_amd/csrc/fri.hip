@@ -1,0 +1,259 @@
+// Openings and FRI for gfx950 (K-eval, K-fricombine, K-frifold, K-pow, query gather of DESIGN.md).
+//
+// Replaces (un-vendored starky 0.4.0 / plonky2 0.2.2, reached from reference src/starks/common/prover.rs:55-65):
+//   StarkOpeningSet::new            - every committed polynomial at zeta and g*zeta (F2), CTL Z's at 1
+//   PolynomialBatch::prove_openings - alpha-batched quotients (F_b(X) - F_b(z_b)) / (X - z_b)
+//   fri_committed_trees             - arity-16 folding with a Merkle tree per layer
+//   fri_proof_of_work               - grinding (smallest witness; upstream takes any)
+//   fri_prover_query_rounds         - leaf rows and Merkle paths at the 84 query indices
+// The reference prover works on coefficients (divide_by_linear, reduce_with_powers, coset FFT per layer).
+// Here everything after the openings stays in the evaluation domain: the batched quotient is formed
+// point-wise on the 2N-point coset from the LDE values that are already resident in HBM, and a layer is
+// folded by interpolating each 16-point coset {x w_16^i} (one leaf = 16 consecutive bit-reversed values)
+// and evaluating at beta.  Both give the same field elements as the coefficient route (the folded
+// polynomial sum_j beta^j P_j(Y) restricted to Y = x^16), with no extension-field FFT at all.
+#include "fri.h"
+#include "poseidon_dev.h"
+
+// ---- openings -----------------------------------------------------------------------------------------------
+// One 256-thread block per polynomial (coefficients, natural order).  out[p] = {P(z0).c0, .c1, P(z1).c0, .c1, P(1)}
+__global__ __launch_bounds__(256) void k_openings(const u64* __restrict__ coeffs, size_t N, gl2 z0, gl2 z1, u64* __restrict__ out) {
+  __shared__ u64 red[256 * 5];
+  const int t = threadIdx.x;
+  const u64* c = coeffs + (size_t)blockIdx.x * N;
+  // P(z) = sum_t z^t * sum_q c[t + 256 q] (z^256)^q
+  const gl2 z0p = gl2_pow(z0, 256), z1p = gl2_pow(z1, 256);
+  gl2 a0 = gl2_make(0, 0), a1 = gl2_make(0, 0);
+  u64 s = 0;
+  for (long q = (long)(N / 256) - 1; q >= 0; q--) {
+    u64 v = c[(size_t)t + 256 * (size_t)q];
+    a0 = gl2_mul(a0, z0p);
+    a0.c0 = gl_add(a0.c0, v);
+    a1 = gl2_mul(a1, z1p);
+    a1.c0 = gl_add(a1.c0, v);
+    s = gl_add(s, v);
+  }
+  a0 = gl2_mul(a0, gl2_pow(z0, (u64)t));
+  a1 = gl2_mul(a1, gl2_pow(z1, (u64)t));
+  red[t] = a0.c0;
+  red[256 + t] = a0.c1;
+  red[512 + t] = a1.c0;
+  red[768 + t] = a1.c1;
+  red[1024 + t] = s;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (t < off)
+      for (int k = 0; k < 5; k++) red[k * 256 + t] = gl_add(red[k * 256 + t], red[k * 256 + t + off]);
+    __syncthreads();
+  }
+  if (t < 5) out[(size_t)blockIdx.x * 5 + t] = red[t * 256];
+}
+
+void fri_openings(const u64* d_coeffs, size_t N, int npolys, gl2 zeta, gl2 zeta_next, u64* d_out, hipStream_t st) {
+  k_openings<<<npolys, 256, 0, st>>>(d_coeffs, N, zeta, zeta_next, d_out);
+}
+
+// ---- batched quotient on the LDE domain ---------------------------------------------------------------
+struct CombineArgs {
+  const u64* tl;   // trace LDE [W][2N]
+  const u64* al;   // aux LDE [A][2N]
+  const u64* ql;   // quotient LDE [4][2N]
+  const u64* apow; // alpha^j as (c0,c1) pairs, j < W + A + 4
+  const u64* xs;   // x_j (bit-reversed order)
+  int W, A, num_lookup;
+  gl2 zeta, zeta_next;
+  gl2 r0, r1, r2;      // F_b(z_b) from the openings
+  gl2 a_n1n2, a_n2;    // alpha^(n1+n2), alpha^(n2)
+  u64* out;            // [2N][2] extension values, bit-reversed order
+  size_t M2;
+};
+
+__global__ __launch_bounds__(256) void k_fri_combine(CombineArgs A) {
+  const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= A.M2) return;
+  const size_t M2 = A.M2;
+  Acc2 g;  // a0 = c0 component, a1 = c1 component of sum alpha^j v_j
+  acc2_init(g);
+  for (int c = 0; c < A.W; c++) acc2_mad(g, A.tl[(size_t)c * M2 + j], A.apow[2 * c], A.apow[2 * c + 1]);
+  const u64* ap = A.apow + 2 * A.W;
+  Acc2 gz;
+  acc2_init(gz);
+  for (int c = 0; c < A.A; c++) {
+    u64 v = A.al[(size_t)c * M2 + j];
+    acc2_mad(g, v, ap[2 * c], ap[2 * c + 1]);
+    if (c >= A.num_lookup) acc2_mad(gz, v, A.apow[2 * (c - A.num_lookup)], A.apow[2 * (c - A.num_lookup) + 1]);
+  }
+  gl2 f1 = gl2_make(acc_red(g.a0), acc_red(g.a1));
+  ap = A.apow + 2 * (A.W + A.A);
+  Acc2 gq;
+  acc2_init(gq);
+  for (int c = 0; c < 4; c++) acc2_mad(gq, A.ql[(size_t)c * M2 + j], ap[2 * c], ap[2 * c + 1]);
+  gl2 f0 = gl2_add(f1, gl2_make(acc_red(gq.a0), acc_red(gq.a1)));
+  gl2 f2 = gl2_make(acc_red(gz.a0), acc_red(gz.a1));
+  const u64 x = A.xs[j];
+  gl2 xe = gl2_make(x, 0);
+  gl2 t0 = gl2_mul(gl2_sub(f0, A.r0), gl2_inv(gl2_sub(xe, A.zeta)));
+  gl2 t1 = gl2_mul(gl2_sub(f1, A.r1), gl2_inv(gl2_sub(xe, A.zeta_next)));
+  gl2 t2 = gl2_mul_base(gl2_sub(f2, A.r2), gl_inv(gl_sub(x, 1)));
+  gl2 r = gl2_add(gl2_add(gl2_mul(t0, A.a_n1n2), gl2_mul(t1, A.a_n2)), t2);
+  reinterpret_cast<ulonglong2*>(A.out)[j] = make_ulonglong2(r.c0, r.c1);
+}
+
+void fri_combine(const StarkShape& sh, const u64* d_tl, const u64* d_al, const u64* d_ql, const u64* d_apow, const u64* d_xs,
+                 gl2 zeta, gl2 zeta_next, gl2 r0, gl2 r1, gl2 r2, gl2 alpha, size_t M2, u64* d_out, hipStream_t st) {
+  CombineArgs A;
+  A.tl = d_tl;
+  A.al = d_al;
+  A.ql = d_ql;
+  A.apow = d_apow;
+  A.xs = d_xs;
+  A.W = sh.W;
+  A.A = sh.n_aux();
+  A.num_lookup = sh.n_lookup_cols();
+  A.zeta = zeta;
+  A.zeta_next = zeta_next;
+  A.r0 = r0;
+  A.r1 = r1;
+  A.r2 = r2;
+  const int n1 = sh.W + sh.n_aux(), n2 = 2 * sh.n_ctl;
+  A.a_n2 = gl2_pow(alpha, n2);
+  A.a_n1n2 = gl2_pow(alpha, n1 + n2);
+  A.out = d_out;
+  A.M2 = M2;
+  k_fri_combine<<<(unsigned)((M2 + 255) / 256), 256, 0, st>>>(A);
+}
+
+// ---- arity-16 fold in the evaluation domain ---------------------------------------------------------------
+// in: M extension values in bit-reversed order on the coset shift*<w_M>; out: M/16 values on shift^16*<w_{M/16}>.
+// inverse 16-point DFT with w_16^-1 = 2^180 (shifts only), component-wise on (c0, c1).
+template <int E>
+__device__ __forceinline__ u64 mul_w16inv(u64 x) {
+  if constexpr (E == 0) return x;
+  else return gl_mul_2exp<192 - 12 * E>(x);
+}
+template <int SPAN, int G, int J>
+__device__ __forceinline__ void ibfly(u64* x) {
+  u64 a = x[G + J], b = x[G + J + SPAN];
+  x[G + J] = gl_add(a, b);
+  x[G + J + SPAN] = mul_w16inv<J * (8 / SPAN)>(gl_sub(a, b));
+}
+__device__ __forceinline__ void idft16(u64* x) {  // natural in, X[k] in x[br4(k)], unscaled
+#define BF(SPAN, G, J) ibfly<SPAN, G, J>(x)
+  BF(8, 0, 0); BF(8, 0, 1); BF(8, 0, 2); BF(8, 0, 3); BF(8, 0, 4); BF(8, 0, 5); BF(8, 0, 6); BF(8, 0, 7);
+  BF(4, 0, 0); BF(4, 0, 1); BF(4, 0, 2); BF(4, 0, 3); BF(4, 8, 0); BF(4, 8, 1); BF(4, 8, 2); BF(4, 8, 3);
+  BF(2, 0, 0); BF(2, 0, 1); BF(2, 4, 0); BF(2, 4, 1); BF(2, 8, 0); BF(2, 8, 1); BF(2, 12, 0); BF(2, 12, 1);
+  BF(1, 0, 0); BF(1, 2, 0); BF(1, 4, 0); BF(1, 6, 0); BF(1, 8, 0); BF(1, 10, 0); BF(1, 12, 0); BF(1, 14, 0);
+#undef BF
+}
+__device__ __forceinline__ constexpr int fbr4(int x) { return ((x & 1) << 3) | ((x & 2) << 1) | ((x & 4) >> 1) | ((x & 8) >> 3); }
+
+__global__ __launch_bounds__(256) void k_fri_fold(const u64* __restrict__ in, u64* __restrict__ out, unsigned log_m, u64 shift,
+                                                  gl2 beta, u64 inv16) {
+  const size_t Mo = (size_t)1 << (log_m - 4);
+  const size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= Mo) return;
+  u64 r0[16], r1[16];
+  const ulonglong2* p = reinterpret_cast<const ulonglong2*>(in) + 16 * c;
+#pragma unroll
+  for (int t = 0; t < 16; t++) {  // position 16c+t holds natural coset index i = br4(t)
+    ulonglong2 v = p[t];
+    r0[fbr4(t)] = v.x;
+    r1[fbr4(t)] = v.y;
+  }
+  idft16(r0);
+  idft16(r1);
+  // coefficients (times 16) of R(x0 * Y): r[br4(m)], m = 0..15.  R(beta) = sum_m coef_m (beta/x0)^m
+  const u32 n0 = bitrev32((u32)c, log_m - 4);
+  const u64 x0 = gl_mul(shift, gl_pow(gl_root_of_unity(log_m), n0));
+  const gl2 y = gl2_mul_base(beta, gl_inv(x0));
+  gl2 acc = gl2_make(0, 0);
+#pragma unroll
+  for (int m = 15; m >= 0; m--) {
+    acc = gl2_mul(acc, y);
+    acc.c0 = gl_add(acc.c0, r0[fbr4(m)]);
+    acc.c1 = gl_add(acc.c1, r1[fbr4(m)]);
+  }
+  acc = gl2_mul_base(acc, inv16);
+  reinterpret_cast<ulonglong2*>(out)[c] = make_ulonglong2(acc.c0, acc.c1);
+}
+
+void fri_fold(const u64* d_in, u64* d_out, unsigned log_m, u64 shift, gl2 beta, u64 inv16, hipStream_t st) {
+  size_t Mo = (size_t)1 << (log_m - 4);
+  k_fri_fold<<<(unsigned)((Mo + 255) / 256), 256, 0, st>>>(d_in, d_out, log_m, shift, beta, inv16);
+}
+
+// ---- proof of work --------------------------------------------------------------------------------------------
+struct PowArgs {
+  u64 state[12];
+  int pos;
+  u64 base;
+  unsigned pow_bits;
+  unsigned long long* result;  // min over valid candidates, initialised to ~0
+};
+__global__ __launch_bounds__(256) void k_pow(PowArgs A) {
+  u64 cand = A.base + (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  u64 s[12];
+#pragma unroll
+  for (int i = 0; i < 12; i++) s[i] = A.state[i];
+  // set_elt(candidate, pos): pos is uniform
+#pragma unroll
+  for (int i = 0; i < 8; i++)
+    if (i == A.pos) s[i] = cand;
+  poseidon_permute(s);
+  if ((s[7] >> (64 - A.pow_bits)) == 0) atomicMin(A.result, (unsigned long long)cand);
+}
+
+void fri_pow_launch(const u64 state[12], int pos, u64 base, unsigned pow_bits, size_t count, unsigned long long* d_result,
+                    hipStream_t st) {
+  PowArgs A;
+  for (int i = 0; i < 12; i++) A.state[i] = state[i];
+  A.pos = pos;
+  A.base = base;
+  A.pow_bits = pow_bits;
+  A.result = d_result;
+  k_pow<<<(unsigned)(count / 256), 256, 0, st>>>(A);
+}
+
+// ---- query gather ---------------------------------------------------------------------------------------------
+// One block per query.  Writes, in proof order: for each initial oracle: leaf row + path; for each layer:
+// 16 extension values + path.
+__global__ __launch_bounds__(256) void k_gather_queries(QueryGatherArgs A) {
+  const int q = blockIdx.x, t = threadIdx.x;
+  u64* out = A.out + (size_t)q * A.words_per_query;
+  size_t x_index = A.indices[q];
+  for (int o = 0; o < 3; o++) {
+    const u64* lde = A.lde[o];
+    const int width = A.width[o];
+    for (int c = t; c < width; c += blockDim.x) out[c] = lde[(size_t)c * A.M2 + x_index];
+    out += width;
+    // Merkle path: sibling at each level
+    const int plen = A.log_m2 - A.cap_height;
+    for (int w = t; w < plen * 4; w += blockDim.x) {
+      int l = w >> 2;
+      size_t node = (x_index >> l) ^ 1;
+      out[w] = A.tree[o][4 * (merkle_level_offset_dev(A.log_m2, l) + node) + (w & 3)];
+    }
+    out += plen * 4;
+  }
+  size_t xi = x_index;
+  int log_m = A.log_m2;
+  for (int l = 0; l < A.n_layers; l++) {
+    size_t ci = xi >> 4;
+    if (t < 32) out[t] = A.layer_vals[l][32 * ci + t];
+    out += 32;
+    const int lg = log_m - 4;  // leaves of this layer's tree
+    const int plen = lg - A.cap_height;
+    for (int w = t; w < plen * 4; w += blockDim.x) {
+      int lv = w >> 2;
+      size_t node = (ci >> lv) ^ 1;
+      out[w] = A.layer_tree[l][4 * (merkle_level_offset_dev(lg, lv) + node) + (w & 3)];
+    }
+    out += plen * 4;
+    xi = ci;
+    log_m = lg;
+  }
+}
+
+void fri_gather_queries(const QueryGatherArgs& A, int n_queries, hipStream_t st) {
+  k_gather_queries<<<n_queries, 256, 0, st>>>(A);
+}

@@ -1,28 +1,587 @@
-// Proving entry points (placeholder until the full pipeline lands in this file).
+// Host orchestration of one STARK proof: the GPU counterpart of the reference's
+//   starks::common::prover::prove                 src/starks/common/prover.rs:18-72
+// followed by starky's prove_with_commitment, as called from G1StarkProofGenerator::run_once
+// (src/generators/g1/stark_proof.rs:151-163).  All polynomial data stays in HBM; the host only runs the
+// Fiat-Shamir transcript on caps / openings (a few KB per round trip) and assembles the proof words.
+#include <algorithm>
+#include <atomic>
+#include <cstring>
+#include <thread>
 #include "ctx.h"
 #include "trace_g1.h"
-extern "C" {
-int bn254s_prove_g1(bn254s_ctx* c, const bn254s_params*, const uint64_t*, const uint64_t*, const uint64_t*, size_t, bn254s_proof**) { if (c) c->err = "not implemented"; return BN254S_E_UNSUPPORTED; }
-int bn254s_prove_g1_batch(bn254s_ctx* c, const bn254s_params*, const uint64_t*, const uint64_t*, const uint64_t*, size_t, size_t, bn254s_proof**) { if (c) c->err = "not implemented"; return BN254S_E_UNSUPPORTED; }
-int bn254s_prove_g2(bn254s_ctx* c, const bn254s_params*, const uint64_t*, const uint64_t*, const uint64_t*, size_t, bn254s_proof**) { if (c) c->err = "not implemented"; return BN254S_E_UNSUPPORTED; }
-int bn254s_prove_fq_exp(bn254s_ctx* c, const bn254s_params*, const uint64_t*, const uint64_t*, const uint64_t*, size_t, bn254s_proof**) { if (c) c->err = "not implemented"; return BN254S_E_UNSUPPORTED; }
-int bn254s_proof_words(const bn254s_proof*, const uint64_t**, size_t*) { return BN254S_E_UNSUPPORTED; }
-int bn254s_proof_degree_bits(const bn254s_proof*) { return 0; }
-int bn254s_proof_outputs(const bn254s_proof*, const uint64_t**, size_t*) { return BN254S_E_UNSUPPORTED; }
-int bn254s_proof_stage_ms(const bn254s_proof*, const float**, size_t*) { return BN254S_E_UNSUPPORTED; }
-const char* bn254s_stage_name(size_t) { return ""; }
-size_t bn254s_proof_serialize(const bn254s_proof*, uint8_t*, size_t) { return 0; }
-void bn254s_proof_free(bn254s_proof*) {}
+#include "aux.h"
+#include "merkle.h"
+#include "quotient.h"
+#include "fri.h"
+#include "transcript.h"
+
+// ---- shapes -------------------------------------------------------------------------------------------------
+StarkShape g1_shape() {  // scalar_mul_view.rs:10-30, scalar_mul_stark.rs:493-500, scalar_mul_ctl.rs:20-55
+  StarkShape s;
+  s.W = G1_W;
+  s.rc_begin = G1_RC_BEGIN;
+  s.rc_end = G1_RC_END;
+  s.table_col = G1_COL_RANGE;
+  s.freq_col = G1_COL_FREQ;
+  s.n_ctl = 2;
+  s.n_constraints = 1111;
+  memset(&s.ctl, 0, sizeof(s.ctl));
+  int m = 0;
+  for (int i = 0; i < 32; i++, m++) { s.ctl.col_start[0][m] = G1_COL_B + i; s.ctl.col_bits[0][m] = 1; }
+  for (int i = 0; i < 32; i++, m++) { s.ctl.col_start[0][m] = G1_COL_A + i; s.ctl.col_bits[0][m] = 1; }
+  for (int k = 0; k < 16; k++, m++) { s.ctl.col_start[0][m] = G1_COL_BITS + 16 * k; s.ctl.col_bits[0][m] = 16; }
+  s.ctl.col_start[0][m] = G1_COL_TIMESTAMP; s.ctl.col_bits[0][m] = 1; m++;
+  s.ctl.ncols[0] = m;
+  s.ctl.filter_col[0] = G1_COL_FLAGS + 0;
+  m = 0;
+  for (int i = 0; i < 32; i++, m++) { s.ctl.col_start[1][m] = G1_COL_SUM + i; s.ctl.col_bits[1][m] = 1; }
+  s.ctl.col_start[1][m] = G1_COL_TIMESTAMP; s.ctl.col_bits[1][m] = 1; m++;
+  s.ctl.ncols[1] = m;
+  s.ctl.filter_col[1] = G1_COL_FLAGS + 1;
+  return s;
 }
+
+// ---- proof object ---------------------------------------------------------------------------------------------
+enum { ST_TRACE = 0, ST_TRACE_COMMIT, ST_AUX, ST_AUX_COMMIT, ST_QUOTIENT, ST_QUOTIENT_COMMIT, ST_OPENINGS, ST_FRI, ST_TOTAL, ST_COUNT };
+static const char* STAGE_NAMES[ST_COUNT] = {"trace_gen", "trace_commit", "aux_columns", "aux_commit", "quotient",
+                                            "quotient_commit", "openings", "fri", "total"};
+
+struct bn254s_proof {
+  std::vector<u64> words, outputs;
+  int degree_bits = 0;
+  float stage_ms[ST_COUNT] = {0};
+};
 
 static size_t rows_for(size_t n, uint32_t min_rows_log2) {
   size_t r = std::max((size_t)1 << min_rows_log2, n * 512), p = 1;
   while (p < r) p <<= 1;
   return p;
 }
+static std::vector<int> fri_arities(const bn254s_params& P, int degree_bits) {  // ConstantArityBits(arity, final)
+  std::vector<int> a;
+  int d = degree_bits;
+  while (d > (int)P.final_poly_bits && d + (int)P.rate_bits - (int)P.arity_bits >= (int)P.cap_height) {
+    a.push_back(P.arity_bits);
+    d -= P.arity_bits;
+  }
+  return a;
+}
 
-extern "C" int bn254s_g1_generate_trace(bn254s_ctx* c, const uint64_t* scalars, const uint64_t* x, const uint64_t* off,
-                                        size_t n, uint32_t min_rows_log2, uint64_t* trace_out, uint64_t* outputs) {
+__global__ __launch_bounds__(256) void k_quotient_chunks(const u64* __restrict__ ab, u64* __restrict__ out, size_t N, u64 inv2,
+                                                         u64 inv2c) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  int a = blockIdx.y;
+  u64 A = ab[(size_t)(a * 2 + 0) * N + i], B = ab[(size_t)(a * 2 + 1) * N + i];
+  out[(size_t)(a * 2 + 0) * N + i] = gl_mul(gl_add(A, B), inv2);
+  out[(size_t)(a * 2 + 1) * N + i] = gl_mul(gl_sub(A, B), inv2c);
+}
+
+#define CHK(call)                                              \
+  do {                                                         \
+    hipError_t e_ = (call);                                    \
+    if (e_ != hipSuccess) {                                    \
+      err = std::string(#call) + ": " + hipGetErrorString(e_); \
+      return BN254S_E_HIP;                                     \
+    }                                                          \
+  } while (0)
+
+// Point tables are per degree; built once per context (bn254s_ctx_create thread or first prove call).
+static int get_point_tables(bn254s_ctx* c, unsigned log_n, QPointTables& pt) {
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lk(mu);
+  std::string key = "pt." + std::to_string(log_n);
+  bool fresh = !c->has(key);
+  size_t M2 = (size_t)2 << log_n;
+  u64* p = c->words(key, 3 * M2);
+  if (!p) return BN254S_E_OOM;
+  if (fresh) {
+    quotient_point_tables(p, p + M2, p + 2 * M2, log_n, c->stream);
+    if (hipStreamSynchronize(c->stream) != hipSuccess) return BN254S_E_HIP;
+  }
+  pt.x = p;
+  pt.lfirst = p + M2;
+  pt.llast = p + 2 * M2;
+  return 0;
+}
+
+static int prove_g1_on_slot(bn254s_ctx* c, Slot& sl, const bn254s_params& P, const u64* scalars, const u64* x, const u64* off,
+                            size_t n, bn254s_proof* pr, std::string& err) {
+  const StarkShape sh = g1_shape();
+  const size_t N = rows_for(n, P.min_rows_log2);
+  if (N != NTT_N) {
+    err = "this build proves 2^16-row traces only (<= 128 instances per proof); use bn254s_prove_g1_batch";
+    return BN254S_E_UNSUPPORTED;
+  }
+  if (P.num_challenges != 2 || P.rate_bits != 1 || P.cap_height != 4 || P.arity_bits != 4 || P.min_rows_log2 < 16 ||
+      P.pow_bits == 0 || P.pow_bits > 32 || P.num_queries == 0 || P.num_queries > 256) {
+    err = "unsupported StarkConfig (only standard_fast_config shapes)";
+    return BN254S_E_UNSUPPORTED;
+  }
+  const unsigned log_n = 16, log_m2 = 17;
+  const size_t M2 = 2 * N;
+  const int W = sh.W, A = sh.n_aux(), NQ = 4, CAPW = 64;
+  const int K = sh.n_total_constraints();
+  hipStream_t st = sl.st;
+  BufPool& mem = sl.mem;
+  QPointTables pt;
+  if (int rc = get_point_tables(c, log_n, pt)) {
+    err = "point tables";
+    return rc;
+  }
+  const std::vector<int> arities = fri_arities(P, log_n);
+  const int L = (int)arities.size();
+  if (L > FRI_MAX_LAYERS) return BN254S_E_UNSUPPORTED;
+
+  // ---- workspace ------------------------------------------------------------------------------------------
+  u64* d_in = mem.words("in", n * 20 + 16);
+  u64* d_tvals = mem.words("tvals", (size_t)W * N);
+  u64* d_tcoef = mem.words("tcoef", (size_t)W * N);
+  u64* d_tmp = mem.words("tmp", (size_t)std::max(W, A) * N);
+  u64* d_tlde = mem.words("tlde", (size_t)W * M2);
+  const size_t tree_words = merkle_tree_digests(log_m2, P.cap_height) * 4;
+  u64* d_trees = mem.words("trees", 3 * tree_words);
+  u64* d_avals = mem.words("avals", (size_t)A * N);
+  u64* d_acoef = mem.words("acoef", (size_t)A * N);
+  u64* d_alde = mem.words("alde", (size_t)A * M2);
+  u64* d_scr = mem.words("scratch", std::max(g1_trace_scratch_words(n), aux_scratch_words(sh, N)));
+  u64* d_q = mem.words("quot", (size_t)(3 * NQ) * N + (size_t)NQ * M2);  // qv, ab, qcoef, qlde
+  u64* d_tabs = mem.words("tabs", 2 * (size_t)K + 5 * 2 * 80 + 2 * (size_t)(W + A + NQ));
+  u64* d_open = mem.words("open", (size_t)(W + A + NQ) * 5);
+  // FRI layer values (extension, 2 words) and trees
+  size_t fri_words = 0, fri_tree_words = 0;
+  {
+    size_t m = M2;
+    for (int l = 0; l <= L; l++) {
+      fri_words += 2 * m;
+      if (l < L) fri_tree_words += merkle_tree_digests((int)log_m2 - 4 * (l + 1), P.cap_height) * 4;
+      m >>= 4;
+    }
+  }
+  u64* d_fri = mem.words("fri", fri_words);
+  u64* d_fritrees = mem.words("fritrees", fri_tree_words);
+  // per-query proof words
+  size_t wpq = (size_t)(W + A + NQ) + 3 * 4 * (log_m2 - P.cap_height);
+  {
+    int lg = log_m2;
+    for (int l = 0; l < L; l++) {
+      lg -= arities[l];
+      wpq += 32 + 4 * (lg - P.cap_height);
+    }
+  }
+  u64* d_qout = mem.words("qout", wpq * P.num_queries + 64);
+  if (!d_in || !d_tvals || !d_tcoef || !d_tmp || !d_tlde || !d_trees || !d_avals || !d_acoef || !d_alde || !d_scr || !d_q ||
+      !d_tabs || !d_open || !d_fri || !d_fritrees || !d_qout) {
+    err = mem.err;
+    return BN254S_E_OOM;
+  }
+  int* d_err = (int*)(d_in + n * 20);
+  unsigned long long* d_pow = (unsigned long long*)(d_in + n * 20 + 2);
+  u32* d_qidx = (u32*)(d_qout + wpq * P.num_queries);
+  u64* d_ttree = d_trees;
+  u64* d_atree = d_trees + tree_words;
+  u64* d_qtree = d_trees + 2 * tree_words;
+  u64* d_qv = d_q;                       // [2][2][N]
+  u64* d_ab = d_q + (size_t)NQ * N;      // [2][2][N]
+  u64* d_qcoef = d_q + (size_t)2 * NQ * N;  // [4][N]
+  u64* d_qlde = d_q + (size_t)3 * NQ * N;   // [4][2N]
+  u64* d_W = d_tabs;
+  u64* d_mzt = d_tabs + 2 * (size_t)K;
+  u64* d_apow = d_mzt + 5 * 2 * 80;
+  const size_t cap_off = 4 * merkle_level_offset(log_m2, log_m2 - P.cap_height);
+
+  hipEvent_t ev[ST_COUNT + 1];
+  for (auto& e : ev) CHK(hipEventCreate(&e));
+  int evi = 0;
+  auto mark = [&]() { hipEventRecord(ev[evi++], st); };
+  auto cleanup_events = [&]() {
+    for (auto& e : ev) hipEventDestroy(e);
+  };
+
+  // ---- trace generation (scalar_mul_stark.rs:55-69) ---------------------------------------------------------
+  mark();
+  CHK(hipMemsetAsync(d_err, 0, 16, st));
+  CHK(hipMemcpyAsync(d_in, scalars, n * 32, hipMemcpyHostToDevice, st));
+  CHK(hipMemcpyAsync(d_in + 4 * n, x, n * 64, hipMemcpyHostToDevice, st));
+  CHK(hipMemcpyAsync(d_in + 12 * n, off, n * 64, hipMemcpyHostToDevice, st));
+  u64* d_outs = d_open;  // n*8 words fit (reused later)
+  if (g1_generate_trace_device(d_in, d_in + 4 * n, d_in + 12 * n, n, d_tvals, N, d_scr, d_outs, d_err, st)) {
+    err = "trace generation launch failed";
+    return BN254S_E_HIP;
+  }
+  pr->outputs.resize(n * 8);
+  int h_err = 0;
+  CHK(hipMemcpyAsync(pr->outputs.data(), d_outs, n * 64, hipMemcpyDeviceToHost, st));
+  CHK(hipMemcpyAsync(&h_err, d_err, 4, hipMemcpyDeviceToHost, st));
+  mark();
+
+  // ---- trace commitment (prover.rs:31-38) -----------------------------------------------------------------
+  ntt_inverse(&c->ntt, d_tvals, d_tcoef, d_tmp, W, st);
+  ntt_lde(&c->ntt, d_tcoef, d_tlde, d_tmp, W, st);
+  merkle_build(d_tlde, 1, M2, W, log_m2, P.cap_height, d_ttree, st);
+  u64 caps[3][64];
+  CHK(hipMemcpyAsync(caps[0], d_ttree + cap_off, CAPW * 8, hipMemcpyDeviceToHost, st));
+  mark();
+  CHK(hipStreamSynchronize(st));
+  if (h_err) {
+    err = "trace generation reported device error " + std::to_string(h_err);
+    cleanup_events();
+    return h_err;
+  }
+
+  // ---- transcript: trace cap, CTL challenges, compact (prover.rs:40-54) --------------------------------
+  Challenger ch;
+  ch.observe_n(caps[0], CAPW);
+  u64 betas[2], gammas[2];
+  for (int i = 0; i < 2; i++) {
+    betas[i] = ch.challenge();
+    gammas[i] = ch.challenge();
+  }
+  u64 init_state[12];
+  ch.compact(init_state);
+
+  // ---- auxiliary columns + commitment ---------------------------------------------------------------------
+  aux_build(sh, d_tvals, N, betas, gammas, d_avals, d_scr, d_err, st);
+  mark();
+  ntt_inverse(&c->ntt, d_avals, d_acoef, d_tmp, A, st);
+  ntt_lde(&c->ntt, d_acoef, d_alde, d_tmp, A, st);
+  merkle_build(d_alde, 1, M2, A, log_m2, P.cap_height, d_atree, st);
+  CHK(hipMemcpyAsync(caps[1], d_atree + cap_off, CAPW * 8, hipMemcpyDeviceToHost, st));
+  mark();
+  CHK(hipStreamSynchronize(st));
+  ch.observe_n(caps[1], CAPW);
+  u64 alphas[2] = {ch.challenge(), 0};
+  alphas[1] = ch.challenge();
+
+  // ---- quotient ---------------------------------------------------------------------------------------------
+  {
+    std::vector<u64> hW, hmzt;
+    g1_quotient_host_tables(sh, alphas, hW, hmzt);
+    CHK(hipMemcpyAsync(d_W, hW.data(), hW.size() * 8, hipMemcpyHostToDevice, st));
+    CHK(hipMemcpyAsync(d_mzt, hmzt.data(), hmzt.size() * 8, hipMemcpyHostToDevice, st));
+    CHK(hipStreamSynchronize(st));  // host vectors go out of scope
+  }
+  g1_quotient_launch(sh, d_tlde, d_alde, d_W, d_mzt, pt, betas, gammas, log_n, d_qv, st);
+  for (int a = 0; a < 2; a++)
+    for (int h = 0; h < 2; h++)
+      ntt_coset_inverse(&c->ntt, h, d_qv + (size_t)(a * 2 + h) * N, d_ab + (size_t)(a * 2 + h) * N, d_tmp, 1, st);
+  {
+    u64 gn = gl_pow(GL_GEN, N);
+    u64 inv2 = gl_inv(2), inv2c = gl_inv(gl_mul(2, gn));
+    dim3 g((unsigned)((N + 255) / 256), 2);
+    k_quotient_chunks<<<g, 256, 0, st>>>(d_ab, d_qcoef, N, inv2, inv2c);
+  }
+  mark();
+  ntt_lde(&c->ntt, d_qcoef, d_qlde, d_tmp, NQ, st);
+  merkle_build(d_qlde, 1, M2, NQ, log_m2, P.cap_height, d_qtree, st);
+  CHK(hipMemcpyAsync(caps[2], d_qtree + cap_off, CAPW * 8, hipMemcpyDeviceToHost, st));
+  mark();
+  CHK(hipStreamSynchronize(st));
+  ch.observe_n(caps[2], CAPW);
+  gl2 zeta = ch.challenge_ext();
+  {
+    gl2 zp = zeta;
+    for (unsigned i = 0; i < log_n; i++) zp = gl2_mul(zp, zp);
+    if (gl2_eq(zp, gl2_make(1, 0))) {
+      err = "Opening point is in the subgroup.";
+      cleanup_events();
+      return BN254S_E_TRANSCRIPT;
+    }
+  }
+  const u64 g = gl_root_of_unity(log_n);
+  gl2 zeta_next = gl2_mul_base(zeta, g);
+
+  // ---- openings (StarkOpeningSet::new) ---------------------------------------------------------------------
+  fri_openings(d_tcoef, N, W, zeta, zeta_next, d_open, st);
+  fri_openings(d_acoef, N, A, zeta, zeta_next, d_open + (size_t)W * 5, st);
+  fri_openings(d_qcoef, N, NQ, zeta, zeta_next, d_open + (size_t)(W + A) * 5, st);
+  std::vector<u64> h_open((size_t)(W + A + NQ) * 5);
+  CHK(hipMemcpyAsync(h_open.data(), d_open, h_open.size() * 8, hipMemcpyDeviceToHost, st));
+  mark();
+  CHK(hipStreamSynchronize(st));
+  const int num_lookup = sh.n_lookup_cols(), n_ctlz = 2 * sh.n_ctl;
+  auto op = [&](int p, int k) { return h_open[(size_t)p * 5 + k]; };
+  // to_fri_openings order: (local | aux | quotient) at zeta, (next | aux_next) at g*zeta, ctl_zs_first
+  for (int p = 0; p < W + A + NQ; p++) {
+    ch.observe(op(p, 0));
+    ch.observe(op(p, 1));
+  }
+  for (int p = 0; p < W + A; p++) {
+    ch.observe(op(p, 2));
+    ch.observe(op(p, 3));
+  }
+  for (int i = 0; i < n_ctlz; i++) {
+    ch.observe(op(W + num_lookup + i, 4));
+    ch.observe(0);
+  }
+
+  // ---- FRI (prove_openings) ------------------------------------------------------------------------------------
+  gl2 fri_alpha = ch.challenge_ext();
+  {
+    std::vector<u64> apow(2 * (size_t)(W + A + NQ));
+    gl2 ap = gl2_make(1, 0), r0 = gl2_make(0, 0), r1 = r0, r2 = r0;
+    for (int p = 0; p < W + A + NQ; p++) {
+      apow[2 * p] = ap.c0;
+      apow[2 * p + 1] = ap.c1;
+      r0 = gl2_add(r0, gl2_mul(ap, gl2_make(op(p, 0), op(p, 1))));
+      if (p < W + A) r1 = gl2_add(r1, gl2_mul(ap, gl2_make(op(p, 2), op(p, 3))));
+      if (p < n_ctlz) r2 = gl2_add(r2, gl2_mul_base(ap, op(W + num_lookup + p, 4)));
+      ap = gl2_mul(ap, fri_alpha);
+    }
+    CHK(hipMemcpyAsync(d_apow, apow.data(), apow.size() * 8, hipMemcpyHostToDevice, st));
+    CHK(hipStreamSynchronize(st));
+    fri_combine(sh, d_tlde, d_alde, d_qlde, d_apow, pt.x, zeta, zeta_next, r0, r1, r2, fri_alpha, M2, d_fri, st);
+  }
+  std::vector<std::vector<u64>> layer_caps(L, std::vector<u64>(CAPW));
+  std::vector<const u64*> layer_vals(L), layer_trees(L);
+  u64* vals = d_fri;
+  u64* ftree = d_fritrees;
+  u64 shift = GL_GEN;
+  unsigned lm = log_m2;
+  const u64 inv16 = gl_inv(16);
+  for (int l = 0; l < L; l++) {
+    const int lg = (int)lm - 4;
+    merkle_build(vals, 32, 1, 32, lg, P.cap_height, ftree, st);
+    CHK(hipMemcpyAsync(layer_caps[l].data(), ftree + 4 * merkle_level_offset(lg, lg - P.cap_height), CAPW * 8,
+                       hipMemcpyDeviceToHost, st));
+    CHK(hipStreamSynchronize(st));
+    ch.observe_n(layer_caps[l].data(), CAPW);
+    gl2 beta = ch.challenge_ext();
+    u64* next = vals + 2 * ((size_t)1 << lm);
+    fri_fold(vals, next, lm, shift, beta, inv16, st);
+    layer_vals[l] = vals;
+    layer_trees[l] = ftree;
+    ftree += merkle_tree_digests(lg, P.cap_height) * 4;
+    vals = next;
+    shift = gl_pow(shift, 16);
+    lm -= 4;
+  }
+  // final polynomial: coset iDFT of the last (tiny) layer on the host, upper half must vanish
+  const size_t Mf = (size_t)1 << lm;
+  std::vector<u64> h_final(2 * Mf);
+  CHK(hipMemcpyAsync(h_final.data(), vals, h_final.size() * 8, hipMemcpyDeviceToHost, st));
+  CHK(hipStreamSynchronize(st));
+  std::vector<gl2> final_poly(Mf >> P.rate_bits);
+  {
+    const u64 w = gl_root_of_unity(lm), winv = gl_inv(w), sinv = gl_inv(shift), minv = gl_inv((u64)Mf);
+    for (size_t k = 0; k < Mf; k++) {
+      gl2 acc = gl2_make(0, 0);
+      u64 wk = gl_pow(winv, k), t = 1;
+      for (size_t nn = 0; nn < Mf; nn++) {  // value at natural index nn sits at position bitrev(nn)
+        size_t pos = bitrev32((u32)nn, lm);
+        acc = gl2_add(acc, gl2_mul_base(gl2_make(h_final[2 * pos], h_final[2 * pos + 1]), t));
+        t = gl_mul(t, wk);
+      }
+      acc = gl2_mul_base(acc, gl_mul(minv, gl_pow(sinv, k)));
+      if (k < final_poly.size()) final_poly[k] = acc;
+      else if (acc.c0 | acc.c1) {
+        err = "FRI final polynomial has non-zero high coefficients";
+        cleanup_events();
+        return BN254S_E_INTERNAL;
+      }
+    }
+  }
+  for (auto& cf : final_poly) {
+    ch.observe(cf.c0);
+    ch.observe(cf.c1);
+  }
+  // proof of work (fri_proof_of_work): smallest witness with >= pow_bits leading zeros in the response
+  u64 pow_witness = 0;
+  {
+    u64 stt[12];
+    memcpy(stt, ch.state, sizeof(stt));
+    for (int i = 0; i < ch.in_len; i++) stt[i] = ch.in_buf[i];
+    const size_t WIN = (size_t)1 << (P.pow_bits + 2);
+    unsigned long long found = ~0ULL;
+    for (u64 base = 0; found == ~0ULL; base += WIN) {
+      CHK(hipMemsetAsync(d_pow, 0xFF, 8, st));
+      fri_pow_launch(stt, ch.in_len, base, P.pow_bits, WIN, d_pow, st);
+      CHK(hipMemcpyAsync(&found, d_pow, 8, hipMemcpyDeviceToHost, st));
+      CHK(hipStreamSynchronize(st));
+      if (base > ((u64)1 << 40)) {
+        err = "proof of work not found";
+        cleanup_events();
+        return BN254S_E_INTERNAL;
+      }
+    }
+    pow_witness = found;
+    ch.observe(pow_witness);
+    u64 resp = ch.challenge();
+    if (resp >> (64 - P.pow_bits)) {
+      err = "proof of work self-check failed";
+      cleanup_events();
+      return BN254S_E_INTERNAL;
+    }
+  }
+  // query rounds
+  std::vector<u32> qidx(P.num_queries);
+  for (auto& q : qidx) q = (u32)(ch.challenge() % M2);
+  CHK(hipMemcpyAsync(d_qidx, qidx.data(), qidx.size() * 4, hipMemcpyHostToDevice, st));
+  {
+    QueryGatherArgs G;
+    G.lde[0] = d_tlde; G.lde[1] = d_alde; G.lde[2] = d_qlde;
+    G.tree[0] = d_ttree; G.tree[1] = d_atree; G.tree[2] = d_qtree;
+    G.width[0] = W; G.width[1] = A; G.width[2] = NQ;
+    for (int l = 0; l < L; l++) {
+      G.layer_vals[l] = layer_vals[l];
+      G.layer_tree[l] = layer_trees[l];
+    }
+    G.n_layers = L;
+    G.log_m2 = log_m2;
+    G.cap_height = P.cap_height;
+    G.M2 = M2;
+    G.indices = d_qidx;
+    G.out = d_qout;
+    G.words_per_query = wpq;
+    fri_gather_queries(G, P.num_queries, st);
+  }
+  std::vector<u64> h_q(wpq * P.num_queries);
+  CHK(hipMemcpyAsync(h_q.data(), d_qout, h_q.size() * 8, hipMemcpyDeviceToHost, st));
+  CHK(hipMemcpyAsync(&h_err, d_err, 4, hipMemcpyDeviceToHost, st));
+  mark();
+  CHK(hipStreamSynchronize(st));
+  CHK(hipGetLastError());
+  if (h_err) {
+    err = "device self-check failed: " + std::to_string(h_err);
+    cleanup_events();
+    return h_err;
+  }
+
+  // ---- assemble (layout: include/bn254_stark.h) ------------------------------------------------------------
+  std::vector<u64>& o = pr->words;
+  o.clear();
+  o.reserve(3 * CAPW + 4 * (W + A) + n_ctlz + 2 * NQ + L * CAPW + h_q.size() + 2 * final_poly.size() + 13);
+  for (int t = 0; t < 3; t++) o.insert(o.end(), caps[t], caps[t] + CAPW);
+  for (int p = 0; p < W; p++) { o.push_back(op(p, 0)); o.push_back(op(p, 1)); }
+  for (int p = 0; p < W; p++) { o.push_back(op(p, 2)); o.push_back(op(p, 3)); }
+  for (int p = W; p < W + A; p++) { o.push_back(op(p, 0)); o.push_back(op(p, 1)); }
+  for (int p = W; p < W + A; p++) { o.push_back(op(p, 2)); o.push_back(op(p, 3)); }
+  for (int i = 0; i < n_ctlz; i++) o.push_back(op(W + num_lookup + i, 4));
+  for (int p = W + A; p < W + A + NQ; p++) { o.push_back(op(p, 0)); o.push_back(op(p, 1)); }
+  for (int l = 0; l < L; l++) o.insert(o.end(), layer_caps[l].begin(), layer_caps[l].end());
+  o.insert(o.end(), h_q.begin(), h_q.end());
+  for (auto& cf : final_poly) { o.push_back(cf.c0); o.push_back(cf.c1); }
+  o.push_back(pow_witness);
+  o.insert(o.end(), init_state, init_state + 12);
+  pr->degree_bits = log_n;
+  for (int i = 0; i + 1 < evi && i < ST_TOTAL; i++) hipEventElapsedTime(&pr->stage_ms[i], ev[i], ev[i + 1]);
+  hipEventElapsedTime(&pr->stage_ms[ST_TOTAL], ev[0], ev[evi - 1]);
+  cleanup_events();
+  return BN254S_OK;
+}
+
+// ---- C ABI ------------------------------------------------------------------------------------------------------
+extern "C" {
+
+int bn254s_prove_g1(bn254s_ctx* c, const bn254s_params* params, const uint64_t* scalars, const uint64_t* x,
+                    const uint64_t* off, size_t n, bn254s_proof** out) {
+  if (!c || !params || !scalars || !x || !off || !out || n == 0 || params->struct_size != sizeof(bn254s_params))
+    return BN254S_E_INVALID_ARG;
+  *out = nullptr;
+  HIP_TRY(c, hipSetDevice(c->device));
+  Slot* sl = c->slot(0);
+  if (!sl) return BN254S_E_HIP;
+  bn254s_proof* pr = new bn254s_proof();
+  int rc = prove_g1_on_slot(c, *sl, *params, scalars, x, off, n, pr, c->err);
+  if (rc != BN254S_OK) {
+    hipStreamSynchronize(sl->st);
+    delete pr;
+    return rc;
+  }
+  *out = pr;
+  return BN254S_OK;
+}
+
+int bn254s_prove_g1_batch(bn254s_ctx* c, const bn254s_params* params, const uint64_t* scalars, const uint64_t* x,
+                          const uint64_t* off, size_t n_total, size_t per_proof, bn254s_proof** proofs_out) {
+  if (!c || !params || !scalars || !x || !off || !proofs_out || n_total == 0 || per_proof == 0 ||
+      params->struct_size != sizeof(bn254s_params))
+    return BN254S_E_INVALID_ARG;
+  const size_t n_proofs = (n_total + per_proof - 1) / per_proof;
+  for (size_t i = 0; i < n_proofs; i++) proofs_out[i] = nullptr;
+  HIP_TRY(c, hipSetDevice(c->device));
+  size_t n_slots = 4;
+  if (const char* e = getenv("BN254S_SLOTS")) n_slots = std::max(1, atoi(e));
+  n_slots = std::min(n_slots, n_proofs);
+  for (size_t s = 0; s < n_slots; s++)
+    if (!c->slot(s)) return BN254S_E_HIP;
+  std::atomic<size_t> next(0);
+  std::atomic<int> first_rc(0);
+  std::vector<std::string> errs(n_slots);
+  std::vector<std::thread> th;
+  for (size_t s = 0; s < n_slots; s++)
+    th.emplace_back([&, s]() {
+      hipSetDevice(c->device);
+      for (;;) {
+        size_t i = next.fetch_add(1);
+        if (i >= n_proofs || first_rc.load() != 0) break;
+        size_t b = i * per_proof, cnt = std::min(per_proof, n_total - b);
+        bn254s_proof* pr = new bn254s_proof();
+        int rc = prove_g1_on_slot(c, *c->slots[s], *params, scalars + 4 * b, x + 8 * b, off + 8 * b, cnt, pr, errs[s]);
+        if (rc != BN254S_OK) {
+          hipStreamSynchronize(c->slots[s]->st);
+          delete pr;
+          int z = 0;
+          first_rc.compare_exchange_strong(z, rc);
+          break;
+        }
+        proofs_out[i] = pr;
+      }
+    });
+  for (auto& t : th) t.join();
+  if (int rc = first_rc.load()) {
+    for (auto& e : errs)
+      if (!e.empty()) c->err = e;
+    for (size_t i = 0; i < n_proofs; i++) {
+      delete proofs_out[i];
+      proofs_out[i] = nullptr;
+    }
+    return rc;
+  }
+  return BN254S_OK;
+}
+
+int bn254s_prove_g2(bn254s_ctx* c, const bn254s_params*, const uint64_t*, const uint64_t*, const uint64_t*, size_t,
+                    bn254s_proof**) {
+  if (c) c->err = "G2 scalar-mul STARK: not implemented in this build";
+  return BN254S_E_UNSUPPORTED;
+}
+int bn254s_prove_fq_exp(bn254s_ctx* c, const bn254s_params*, const uint64_t*, const uint64_t*, const uint64_t*, size_t,
+                        bn254s_proof**) {
+  if (c) c->err = "Fq exponentiation STARK: not implemented in this build";
+  return BN254S_E_UNSUPPORTED;
+}
+
+int bn254s_proof_words(const bn254s_proof* p, const uint64_t** data, size_t* len) {
+  if (!p || !data || !len) return BN254S_E_INVALID_ARG;
+  *data = p->words.data();
+  *len = p->words.size();
+  return BN254S_OK;
+}
+int bn254s_proof_degree_bits(const bn254s_proof* p) { return p ? p->degree_bits : 0; }
+int bn254s_proof_outputs(const bn254s_proof* p, const uint64_t** data, size_t* len) {
+  if (!p || !data || !len) return BN254S_E_INVALID_ARG;
+  *data = p->outputs.data();
+  *len = p->outputs.size();
+  return BN254S_OK;
+}
+int bn254s_proof_stage_ms(const bn254s_proof* p, const float** ms, size_t* n_stages) {
+  if (!p || !ms || !n_stages) return BN254S_E_INVALID_ARG;
+  *ms = p->stage_ms;
+  *n_stages = ST_COUNT;
+  return BN254S_OK;
+}
+const char* bn254s_stage_name(size_t stage) { return stage < ST_COUNT ? STAGE_NAMES[stage] : ""; }
+size_t bn254s_proof_serialize(const bn254s_proof* p, uint8_t* buf, size_t cap) {
+  if (!p) return 0;
+  size_t need = p->words.size() * 8;
+  if (buf && cap >= need) memcpy(buf, p->words.data(), need);  // hosts are little-endian
+  return need;
+}
+void bn254s_proof_free(bn254s_proof* p) { delete p; }
+
+int bn254s_g1_generate_trace(bn254s_ctx* c, const uint64_t* scalars, const uint64_t* x, const uint64_t* off, size_t n,
+                             uint32_t min_rows_log2, uint64_t* trace_out, uint64_t* outputs) {
   if (!c || !scalars || !x || !off || n == 0 || !trace_out) return BN254S_E_INVALID_ARG;
   if (min_rows_log2 < 16) {  // the range-check table needs all 2^16 values (scalar_mul_stark.rs:71-87)
     c->err = "min_rows_log2 must be >= 16";
@@ -55,3 +614,5 @@ extern "C" int bn254s_g1_generate_trace(bn254s_ctx* c, const uint64_t* scalars, 
   }
   return BN254S_OK;
 }
+
+}  // extern "C"

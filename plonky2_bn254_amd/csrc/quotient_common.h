@@ -1,0 +1,133 @@
+// Shared pieces of the quotient (constraint-evaluation) kernels.
+//
+// starky's ConstraintConsumer folds the constraint stream c_0, c_1, ... Horner-style:
+//   acc_j <- acc_j * alpha_j + c_e          (consumer.constraint)
+// so after K constraints acc_j = sum_e c_e * alpha_j^(K-1-e).  The emission ORDER is therefore part of the
+// transcript; the kernels keep it by numbering constraints exactly in the order of the reference's
+// eval_packed_generic and multiplying each by the precomputed weight W_j[e] = alpha_j^(K-1-e).  Weights are
+// uniform over the grid (scalar loads); products are accumulated un-reduced in 128+ bits.
+#pragma once
+#include "gl_dev.h"
+#include "aux.h"
+
+struct Acc {  // lazy accumulator: value = lo + hi*2^64 + ov*2^128
+  u64 lo, hi;
+  u32 ov;
+};
+__device__ __forceinline__ void acc_init(Acc& a) {
+  a.lo = 0;
+  a.hi = 0;
+  a.ov = 0;
+}
+__device__ __forceinline__ void acc_mad(Acc& a, u64 x, u64 w) {
+  u64 pl = x * w, ph = __umul64hi(x, w);
+  a.lo += pl;
+  u64 c = a.lo < pl ? 1 : 0;
+  u64 h = a.hi + ph;
+  u32 o = h < ph ? 1 : 0;
+  h += c;
+  o += h < c ? 1 : 0;
+  a.hi = h;
+  a.ov += o;
+}
+__device__ __forceinline__ u64 acc_red(const Acc& a) {
+  // 2^128 = -2^32 (mod p); ov stays far below 2^32
+  return gl_sub(gl_reduce128(a.lo, a.hi), ((u64)a.ov) << 32);
+}
+struct Acc2 {
+  Acc a0, a1;
+};
+__device__ __forceinline__ void acc2_init(Acc2& a) {
+  acc_init(a.a0);
+  acc_init(a.a1);
+}
+__device__ __forceinline__ void acc2_mad(Acc2& a, u64 x, u64 w0, u64 w1) {
+  acc_mad(a.a0, x, w0);
+  acc_mad(a.a1, x, w1);
+}
+
+// Per-LDE-point constants in bit-reversed (Merkle leaf) order, built once per context.
+struct QPointTables {
+  const u64* x;       // x_j = shift_h * w_N^k,  j = h*N + bitrev(k)
+  const u64* lfirst;  // L_first(x_j)
+  const u64* llast;   // L_last(x_j)
+};
+
+// position of the "next" row (natural index + 2, i.e. k + 1 on the same coset) in bit-reversed order
+__device__ __forceinline__ size_t next_position(size_t j, unsigned log_n) {
+  const size_t N = (size_t)1 << log_n;
+  size_t h = j >> log_n;
+  u32 k = bitrev32((u32)(j & (N - 1)), log_n);
+  k = (k + 1) & (u32)(N - 1);
+  return (h << log_n) | bitrev32(k, log_n);
+}
+
+// LogUp constraints of both challenges (starky eval_packed_lookups_generic) followed by the
+// CTL constraints (eval_cross_table_lookup_checks, A.7).  e0 = index of the first of these constraints.
+__device__ __forceinline__ void lookup_and_ctl_constraints(const StarkShape& sh, const u64* __restrict__ tl,
+                                                           const u64* __restrict__ al, size_t M2, size_t j, size_t jn,
+                                                           const u64* __restrict__ W0, const u64* __restrict__ W1, int e0,
+                                                           const u64 betas[2], const u64 gammas[2], u64 lfirst, u64 llast,
+                                                           u64 z_last, u64& tot0, u64& tot1) {
+  const int m = sh.n_helpers(), n_rc = sh.n_rc();
+  int e = e0;
+  Acc2 acc;
+  acc2_init(acc);
+  const u64 table = tl[(size_t)sh.table_col * M2 + j], freq = tl[(size_t)sh.freq_col * M2 + j];
+  u64 hs[2] = {0, 0};
+  for (int k = 0; k < m; k++) {
+    u64 f0 = tl[(size_t)(sh.rc_begin + 2 * k) * M2 + j];
+    bool two = (2 * k + 1) < n_rc;
+    u64 f1 = two ? tl[(size_t)(sh.rc_begin + 2 * k + 1) * M2 + j] : 0;
+#pragma unroll
+    for (int ch = 0; ch < 2; ch++) {
+      u64 h = al[(size_t)(ch * (m + 1) + k) * M2 + j];
+      u64 g0 = gl_add(f0, betas[ch]);
+      u64 c;
+      if (two) {
+        u64 g1 = gl_add(f1, betas[ch]);
+        c = gl_sub(gl_sub(gl_mul(gl_mul(g1, g0), h), g1), g0);
+      } else {
+        c = gl_sub(gl_mul(g0, h), 1);
+      }
+      int ee = e0 + ch * (m + 2) + k;
+      acc2_mad(acc, c, W0[ee], W1[ee]);
+      hs[ch] = gl_add(hs[ch], h);
+    }
+  }
+#pragma unroll
+  for (int ch = 0; ch < 2; ch++) {
+    u64 z = al[(size_t)(ch * (m + 1) + m) * M2 + j], nz = al[(size_t)(ch * (m + 1) + m) * M2 + jn];
+    u64 twc = gl_add(table, betas[ch]);
+    u64 y = gl_sub(gl_mul(hs[ch], twc), freq);
+    int ee = e0 + ch * (m + 2) + m;
+    acc2_mad(acc, gl_mul(z, lfirst), W0[ee], W1[ee]);
+    acc2_mad(acc, gl_sub(gl_mul(gl_sub(nz, z), twc), y), W0[ee + 1], W1[ee + 1]);
+  }
+  e = e0 + 2 * (m + 2);
+  // CTL: one Z per (ctl, challenge), no helper columns
+  for (int ctl = 0; ctl < sh.n_ctl; ctl++) {
+    u64 a0 = 0, a1 = 0;
+    for (int mm = sh.ctl.ncols[ctl] - 1; mm >= 0; mm--) {
+      int start = sh.ctl.col_start[ctl][mm], nb = sh.ctl.col_bits[ctl][mm];
+      u64 v = 0;
+      for (int b = nb - 1; b >= 0; b--) v = gl_add(gl_dbl(v), tl[(size_t)(start + b) * M2 + j]);
+      a0 = gl_add(gl_mul(a0, betas[0]), v);
+      a1 = gl_add(gl_mul(a1, betas[1]), v);
+    }
+    u64 comb[2] = {gl_add(a0, gammas[0]), gl_add(a1, gammas[1])};
+    u64 f0 = tl[(size_t)sh.ctl.filter_col[ctl] * M2 + j];
+#pragma unroll
+    for (int ch = 0; ch < 2; ch++) {
+      int zc = 2 * (m + 1) + ctl * 2 + ch;
+      u64 lz = al[(size_t)zc * M2 + j], nz = al[(size_t)zc * M2 + jn];
+      u64 c_last = gl_mul(gl_sub(gl_mul(comb[ch], lz), f0), llast);
+      u64 c_tr = gl_mul(gl_sub(gl_mul(comb[ch], gl_sub(lz, nz)), f0), z_last);
+      acc2_mad(acc, c_last, W0[e], W1[e]);
+      acc2_mad(acc, c_tr, W0[e + 1], W1[e + 1]);
+      e += 2;
+    }
+  }
+  tot0 = gl_add(tot0, acc_red(acc.a0));
+  tot1 = gl_add(tot1, acc_red(acc.a1));
+}
