@@ -15,3 +15,7 @@ static inline size_t merkle_tree_digests(int log_leaves, int cap_height) { retur
 // and build all levels up to the cap.  tree must hold merkle_tree_digests() * 4 words.
 void merkle_build(const u64* data, size_t leaf_stride, size_t elem_stride, int leaf_len, int log_leaves, int cap_height,
                   u64* tree, hipStream_t s);
+// The two halves of merkle_build: leaf digests only (GPU-saturating) and the upper levels (latency-bound).
+void merkle_leaves(const u64* data, size_t leaf_stride, size_t elem_stride, int leaf_len, int log_leaves, u64* tree,
+                   hipStream_t s);
+void merkle_upper(int log_leaves, int cap_height, u64* tree, hipStream_t s);

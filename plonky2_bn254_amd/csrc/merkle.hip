@@ -48,14 +48,23 @@ __global__ __launch_bounds__(256) void k_merkle_level(const u64* __restrict__ in
   o[1] = make_ulonglong2(s[2], s[3]);
 }
 
-void merkle_build(const u64* data, size_t leaf_stride, size_t elem_stride, int leaf_len, int log_leaves, int cap_height,
-                  u64* tree, hipStream_t s) {
+void merkle_leaves(const u64* data, size_t leaf_stride, size_t elem_stride, int leaf_len, int log_leaves, u64* tree,
+                   hipStream_t s) {
   size_t n = (size_t)1 << log_leaves;
   k_leaf_hash<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(data, leaf_stride, elem_stride, leaf_len, n, tree);
+}
+
+void merkle_upper(int log_leaves, int cap_height, u64* tree, hipStream_t s) {
   for (int l = 0; l < log_leaves - cap_height; l++) {
     size_t n_out = (size_t)1 << (log_leaves - l - 1);
     const u64* in = tree + 4 * merkle_level_offset(log_leaves, l);
     u64* out = tree + 4 * merkle_level_offset(log_leaves, l + 1);
     k_merkle_level<<<(unsigned)((n_out + 255) / 256), 256, 0, s>>>(in, out, n_out);
   }
+}
+
+void merkle_build(const u64* data, size_t leaf_stride, size_t elem_stride, int leaf_len, int log_leaves, int cap_height,
+                  u64* tree, hipStream_t s) {
+  merkle_leaves(data, leaf_stride, elem_stride, leaf_len, log_leaves, tree, s);
+  merkle_upper(log_leaves, cap_height, tree, s);
 }

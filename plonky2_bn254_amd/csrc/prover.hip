@@ -42,9 +42,10 @@ StarkShape g1_shape() {  // scalar_mul_view.rs:10-30, scalar_mul_stark.rs:493-50
 }
 
 // ---- proof object ---------------------------------------------------------------------------------------------
-enum { ST_TRACE = 0, ST_TRACE_COMMIT, ST_AUX, ST_AUX_COMMIT, ST_QUOTIENT, ST_QUOTIENT_COMMIT, ST_OPENINGS, ST_FRI, ST_TOTAL, ST_COUNT };
-static const char* STAGE_NAMES[ST_COUNT] = {"trace_gen", "trace_commit", "aux_columns", "aux_commit", "quotient",
-                                            "quotient_commit", "openings", "fri", "total"};
+enum { ST_TRACE = 0, ST_TRACE_NTT, ST_TRACE_MERKLE, ST_AUX, ST_AUX_NTT, ST_AUX_MERKLE, ST_QUOTIENT, ST_QUOTIENT_COMMIT,
+       ST_OPENINGS, ST_FRI, ST_TOTAL, ST_COUNT };
+static const char* STAGE_NAMES[ST_COUNT] = {"trace_gen", "trace_ntt", "trace_merkle", "aux_columns", "aux_ntt", "aux_merkle",
+                                            "quotient", "quotient_commit", "openings", "fri", "total"};
 
 struct bn254s_proof {
   std::vector<u64> words, outputs;
@@ -85,6 +86,17 @@ __global__ __launch_bounds__(256) void k_quotient_chunks(const u64* __restrict__
       return BN254S_E_HIP;                                     \
     }                                                          \
   } while (0)
+
+// Holds the context's big-kernel lock; on release waits until the slot's stream has drained.
+struct BigSection {
+  bn254s_ctx* c;
+  hipStream_t st;
+  BigSection(bn254s_ctx* c_, hipStream_t st_) : c(c_), st(st_) { c->big_mu.lock(); }
+  ~BigSection() {
+    hipStreamSynchronize(st);
+    c->big_mu.unlock();
+  }
+};
 
 // Point tables are per degree; built once per context (bn254s_ctx_create thread or first prove call).
 static int get_point_tables(bn254s_ctx* c, unsigned log_n, QPointTables& pt) {
@@ -190,16 +202,18 @@ static int prove_g1_on_slot(bn254s_ctx* c, Slot& sl, const bn254s_params& P, con
   u64* d_apow = d_mzt + 5 * 2 * 80;
   const size_t cap_off = 4 * merkle_level_offset(log_m2, log_m2 - P.cap_height);
 
-  hipEvent_t ev[ST_COUNT + 1];
+  hipEvent_t ev[2 * ST_COUNT];
   for (auto& e : ev) CHK(hipEventCreate(&e));
-  int evi = 0;
-  auto mark = [&]() { hipEventRecord(ev[evi++], st); };
+  // one begin/end event pair per stage; a stage's time never includes waiting for the big-kernel lock
+  auto sb = [&](int stage) { hipEventRecord(ev[2 * stage], st); };
+  auto se = [&](int stage) { hipEventRecord(ev[2 * stage + 1], st); };
   auto cleanup_events = [&]() {
     for (auto& e : ev) hipEventDestroy(e);
   };
 
   // ---- trace generation (scalar_mul_stark.rs:55-69) ---------------------------------------------------------
-  mark();
+  sb(ST_TOTAL);
+  sb(ST_TRACE);
   CHK(hipMemsetAsync(d_err, 0, 16, st));
   CHK(hipMemcpyAsync(d_in, scalars, n * 32, hipMemcpyHostToDevice, st));
   CHK(hipMemcpyAsync(d_in + 4 * n, x, n * 64, hipMemcpyHostToDevice, st));
@@ -213,15 +227,22 @@ static int prove_g1_on_slot(bn254s_ctx* c, Slot& sl, const bn254s_params& P, con
   int h_err = 0;
   CHK(hipMemcpyAsync(pr->outputs.data(), d_outs, n * 64, hipMemcpyDeviceToHost, st));
   CHK(hipMemcpyAsync(&h_err, d_err, 4, hipMemcpyDeviceToHost, st));
-  mark();
+  se(ST_TRACE);
 
   // ---- trace commitment (prover.rs:31-38) -----------------------------------------------------------------
-  ntt_inverse(&c->ntt, d_tvals, d_tcoef, d_tmp, W, st);
-  ntt_lde(&c->ntt, d_tcoef, d_tlde, d_tmp, W, st);
-  merkle_build(d_tlde, 1, M2, W, log_m2, P.cap_height, d_ttree, st);
+  {
+    BigSection big(c, st);
+    sb(ST_TRACE_NTT);
+    ntt_inverse(&c->ntt, d_tvals, d_tcoef, d_tmp, W, st);
+    ntt_lde(&c->ntt, d_tcoef, d_tlde, d_tmp, W, st);
+    se(ST_TRACE_NTT);
+    sb(ST_TRACE_MERKLE);
+    merkle_leaves(d_tlde, 1, M2, W, log_m2, d_ttree, st);
+  }
+  merkle_upper(log_m2, P.cap_height, d_ttree, st);
   u64 caps[3][64];
   CHK(hipMemcpyAsync(caps[0], d_ttree + cap_off, CAPW * 8, hipMemcpyDeviceToHost, st));
-  mark();
+  se(ST_TRACE_MERKLE);
   CHK(hipStreamSynchronize(st));
   if (h_err) {
     err = "trace generation reported device error " + std::to_string(h_err);
@@ -241,13 +262,21 @@ static int prove_g1_on_slot(bn254s_ctx* c, Slot& sl, const bn254s_params& P, con
   ch.compact(init_state);
 
   // ---- auxiliary columns + commitment ---------------------------------------------------------------------
-  aux_build(sh, d_tvals, N, betas, gammas, d_avals, d_scr, d_err, st);
-  mark();
-  ntt_inverse(&c->ntt, d_avals, d_acoef, d_tmp, A, st);
-  ntt_lde(&c->ntt, d_acoef, d_alde, d_tmp, A, st);
-  merkle_build(d_alde, 1, M2, A, log_m2, P.cap_height, d_atree, st);
+  {
+    BigSection big(c, st);
+    sb(ST_AUX);
+    aux_build(sh, d_tvals, N, betas, gammas, d_avals, d_scr, d_err, st);
+    se(ST_AUX);
+    sb(ST_AUX_NTT);
+    ntt_inverse(&c->ntt, d_avals, d_acoef, d_tmp, A, st);
+    ntt_lde(&c->ntt, d_acoef, d_alde, d_tmp, A, st);
+    se(ST_AUX_NTT);
+    sb(ST_AUX_MERKLE);
+    merkle_leaves(d_alde, 1, M2, A, log_m2, d_atree, st);
+  }
+  merkle_upper(log_m2, P.cap_height, d_atree, st);
   CHK(hipMemcpyAsync(caps[1], d_atree + cap_off, CAPW * 8, hipMemcpyDeviceToHost, st));
-  mark();
+  se(ST_AUX_MERKLE);
   CHK(hipStreamSynchronize(st));
   ch.observe_n(caps[1], CAPW);
   u64 alphas[2] = {ch.challenge(), 0};
@@ -261,7 +290,11 @@ static int prove_g1_on_slot(bn254s_ctx* c, Slot& sl, const bn254s_params& P, con
     CHK(hipMemcpyAsync(d_mzt, hmzt.data(), hmzt.size() * 8, hipMemcpyHostToDevice, st));
     CHK(hipStreamSynchronize(st));  // host vectors go out of scope
   }
-  g1_quotient_launch(sh, d_tlde, d_alde, d_W, d_mzt, pt, betas, gammas, log_n, d_qv, st);
+  {
+    BigSection big(c, st);
+    sb(ST_QUOTIENT);
+    g1_quotient_launch(sh, d_tlde, d_alde, d_W, d_mzt, pt, betas, gammas, log_n, d_qv, st);
+  }
   for (int a = 0; a < 2; a++)
     for (int h = 0; h < 2; h++)
       ntt_coset_inverse(&c->ntt, h, d_qv + (size_t)(a * 2 + h) * N, d_ab + (size_t)(a * 2 + h) * N, d_tmp, 1, st);
@@ -271,11 +304,12 @@ static int prove_g1_on_slot(bn254s_ctx* c, Slot& sl, const bn254s_params& P, con
     dim3 g((unsigned)((N + 255) / 256), 2);
     k_quotient_chunks<<<g, 256, 0, st>>>(d_ab, d_qcoef, N, inv2, inv2c);
   }
-  mark();
+  se(ST_QUOTIENT);
+  sb(ST_QUOTIENT_COMMIT);
   ntt_lde(&c->ntt, d_qcoef, d_qlde, d_tmp, NQ, st);
   merkle_build(d_qlde, 1, M2, NQ, log_m2, P.cap_height, d_qtree, st);
   CHK(hipMemcpyAsync(caps[2], d_qtree + cap_off, CAPW * 8, hipMemcpyDeviceToHost, st));
-  mark();
+  se(ST_QUOTIENT_COMMIT);
   CHK(hipStreamSynchronize(st));
   ch.observe_n(caps[2], CAPW);
   gl2 zeta = ch.challenge_ext();
@@ -292,12 +326,16 @@ static int prove_g1_on_slot(bn254s_ctx* c, Slot& sl, const bn254s_params& P, con
   gl2 zeta_next = gl2_mul_base(zeta, g);
 
   // ---- openings (StarkOpeningSet::new) ---------------------------------------------------------------------
-  fri_openings(d_tcoef, N, W, zeta, zeta_next, d_open, st);
-  fri_openings(d_acoef, N, A, zeta, zeta_next, d_open + (size_t)W * 5, st);
-  fri_openings(d_qcoef, N, NQ, zeta, zeta_next, d_open + (size_t)(W + A) * 5, st);
+  {
+    BigSection big(c, st);
+    sb(ST_OPENINGS);
+    fri_openings(d_tcoef, N, W, zeta, zeta_next, d_open, st);
+    fri_openings(d_acoef, N, A, zeta, zeta_next, d_open + (size_t)W * 5, st);
+    fri_openings(d_qcoef, N, NQ, zeta, zeta_next, d_open + (size_t)(W + A) * 5, st);
+  }
   std::vector<u64> h_open((size_t)(W + A + NQ) * 5);
   CHK(hipMemcpyAsync(h_open.data(), d_open, h_open.size() * 8, hipMemcpyDeviceToHost, st));
-  mark();
+  se(ST_OPENINGS);
   CHK(hipStreamSynchronize(st));
   const int num_lookup = sh.n_lookup_cols(), n_ctlz = 2 * sh.n_ctl;
   auto op = [&](int p, int k) { return h_open[(size_t)p * 5 + k]; };
@@ -330,6 +368,8 @@ static int prove_g1_on_slot(bn254s_ctx* c, Slot& sl, const bn254s_params& P, con
     }
     CHK(hipMemcpyAsync(d_apow, apow.data(), apow.size() * 8, hipMemcpyHostToDevice, st));
     CHK(hipStreamSynchronize(st));
+    BigSection big(c, st);
+    sb(ST_FRI);
     fri_combine(sh, d_tlde, d_alde, d_qlde, d_apow, pt.x, zeta, zeta_next, r0, r1, r2, fri_alpha, M2, d_fri, st);
   }
   std::vector<std::vector<u64>> layer_caps(L, std::vector<u64>(CAPW));
@@ -438,7 +478,8 @@ static int prove_g1_on_slot(bn254s_ctx* c, Slot& sl, const bn254s_params& P, con
   std::vector<u64> h_q(wpq * P.num_queries);
   CHK(hipMemcpyAsync(h_q.data(), d_qout, h_q.size() * 8, hipMemcpyDeviceToHost, st));
   CHK(hipMemcpyAsync(&h_err, d_err, 4, hipMemcpyDeviceToHost, st));
-  mark();
+  se(ST_FRI);
+  se(ST_TOTAL);
   CHK(hipStreamSynchronize(st));
   CHK(hipGetLastError());
   if (h_err) {
@@ -464,8 +505,7 @@ static int prove_g1_on_slot(bn254s_ctx* c, Slot& sl, const bn254s_params& P, con
   o.push_back(pow_witness);
   o.insert(o.end(), init_state, init_state + 12);
   pr->degree_bits = log_n;
-  for (int i = 0; i + 1 < evi && i < ST_TOTAL; i++) hipEventElapsedTime(&pr->stage_ms[i], ev[i], ev[i + 1]);
-  hipEventElapsedTime(&pr->stage_ms[ST_TOTAL], ev[0], ev[evi - 1]);
+  for (int i = 0; i < ST_COUNT; i++) hipEventElapsedTime(&pr->stage_ms[i], ev[2 * i], ev[2 * i + 1]);
   cleanup_events();
   return BN254S_OK;
 }

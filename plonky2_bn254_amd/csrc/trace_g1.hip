@@ -379,17 +379,44 @@ __global__ __launch_bounds__(64) void k_g1_rows(const u64* __restrict__ scalars,
 }
 
 // ---- range-check columns (generate_range_checks, scalar_mul_stark.rs:71-87) ----------------------------
-__global__ __launch_bounds__(256) void k_histogram(const u64* __restrict__ trace, size_t N, int col_begin, int col_end,
-                                                   u32* __restrict__ hist, int* __restrict__ err) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  size_t total = (size_t)(col_end - col_begin) * N;
-  for (; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    u64 v = trace[(size_t)col_begin * N + i];
-    if (v >= 65536) {
-      atomicCAS(err, 0, BN254S_E_INTERNAL);
-      continue;
+// LDS-privatised histogram.  blockIdx.y selects the half of the 2^16 bins kept in LDS (32768 u32 = 128 KB);
+// every block sweeps its slice of the range-checked columns once per half.  The witness columns are far from
+// uniform (aux_hi limbs sit at 2^13 +- 1, many flags are 0/1), so before touching LDS each wave peels off up to
+// two "leader" values with ballots and adds their multiplicity with one atomic.
+__global__ __launch_bounds__(1024) void k_histogram(const u64* __restrict__ trace, size_t N, int col_begin, int col_end,
+                                                    u32* __restrict__ hist, int* __restrict__ err) {
+  __shared__ u32 h[32768];
+  const u32 half = blockIdx.y;
+  for (int b = threadIdx.x; b < 32768; b += blockDim.x) h[b] = 0;
+  __syncthreads();
+  const size_t total = (size_t)(col_end - col_begin) * N;
+  const size_t per = (total + gridDim.x - 1) / gridDim.x;
+  const size_t lo = (size_t)blockIdx.x * per, hi = min(total, lo + per);
+  const u64* src = trace + (size_t)col_begin * N;
+  const int lane = threadIdx.x & 63;
+  for (size_t base = lo; base < hi; base += blockDim.x) {
+    size_t i = base + threadIdx.x;
+    u64 v = i < hi ? src[i] : ~0ULL;
+    if (i < hi && v >= 65536) atomicCAS(err, 0, BN254S_E_INTERNAL);
+    bool active = i < hi && (v >> 15) == half;
+    u32 bin = (u32)v & 32767;
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+      unsigned long long m = __ballot(active);
+      if (m == 0) break;
+      int leader = __ffsll((long long)m) - 1;
+      u32 lv = __shfl(bin, leader);
+      bool same = active && bin == lv;
+      unsigned long long ms = __ballot(same);
+      if (lane == leader) atomicAdd(&h[lv], (u32)__popcll(ms));
+      active = active && !same;
     }
-    atomicAdd(&hist[v], 1u);
+    if (active) atomicAdd(&h[bin], 1u);
+  }
+  __syncthreads();
+  for (int b = threadIdx.x; b < 32768; b += blockDim.x) {
+    u32 cnt = h[b];
+    if (cnt) atomicAdd(&hist[half * 32768 + b], cnt);
   }
 }
 __global__ __launch_bounds__(256) void k_range_columns(u64* __restrict__ trace, size_t N, int freq_col, int range_col,
@@ -447,7 +474,7 @@ int g1_generate_trace_device(const u64* d_scalars, const u64* d_x, const u64* d_
     k_fq_batch_inv<CH><<<(unsigned)((threads + 63) / 64), 64, 0, st>>>(den, deninv, nrows);
   }
   k_g1_rows<<<(unsigned)((nrows + 63) / 64), 64, 0, st>>>(d_scalars, (int)n, px, py, zi, deninv, rf, d_trace, N, d_err);
-  k_histogram<<<2048, 256, 0, st>>>(d_trace, N, G1_RC_BEGIN, G1_RC_END, hist, d_err);
+  k_histogram<<<dim3(128, 2), 1024, 0, st>>>(d_trace, N, G1_RC_BEGIN, G1_RC_END, hist, d_err);
   k_range_columns<<<(unsigned)((N + 255) / 256), 256, 0, st>>>(d_trace, N, G1_COL_FREQ, G1_COL_RANGE, hist);
   if (d_outputs) k_g1_outputs<<<(unsigned)((n + 63) / 64), 64, 0, st>>>(d_scalars, (int)n, px, py, zi, d_outputs);
   return hipGetLastError() == hipSuccess ? 0 : -1;

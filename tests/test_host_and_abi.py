@@ -1,0 +1,62 @@
+"""CPU tests: host-side logic and the C ABI surface (no compute calls without a GPU)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import plonky2_bn254_amd as pk
+from plonky2_bn254_amd import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "bn254_stark.h")).read()
+    declared = sorted(set(re.findall(r"\b(bn254s_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(declared) >= 18
+    lib = ctypes.CDLL(pk.lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in bn254_stark.h but not exported"
+    assert lib.bn254s_abi_version() == 1
+
+
+def test_default_params_are_standard_fast_config():
+    p = pk.default_params()
+    assert (p.security_bits, p.num_challenges, p.rate_bits, p.cap_height, p.pow_bits, p.arity_bits, p.final_poly_bits,
+            p.num_queries, p.min_rows_log2) == (100, 2, 1, 4, 16, 4, 5, 84, 16)
+    assert p.struct_size == ctypes.sizeof(pk.lib.Params)
+
+
+def test_context_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(RuntimeError):
+        pk.Context(0)
+
+
+def test_missing_library_is_an_error(monkeypatch):
+    monkeypatch.setattr(pk.lib, "_lib", None)
+    monkeypatch.setattr(pk.lib, "LIB_PATH", "/nonexistent/libbn254stark.so")
+    with pytest.raises(pk.LibraryMissing):
+        pk.load_library()
+
+
+def test_synthetic_inputs_are_deterministic_and_on_curve():
+    s1, x1, o1 = synth.g1_inputs(4)
+    s2, x2, o2 = synth.g1_inputs(4)
+    assert np.array_equal(s1, s2) and np.array_equal(x1, x2) and np.array_equal(o1, o2)
+    for pt in list(x1) + list(o1):
+        px, py = synth.words_to_int(pt[:4]), synth.words_to_int(pt[4:])
+        assert (py * py - px * px * px - 3) % synth.P == 0
+    assert synth.g1_mul(synth.R_ORDER - 1, synth.G1_GEN) == (1, synth.P - 2)
+
+
+def test_oracle_proof_length_formula(oracle):
+    # 3 caps, openings, 3 FRI caps, 84 query rounds, 16 final coefficients, pow witness, 12-word state
+    W, A = 781, 456
+    per_q = (W + A + 4) + 3 * 13 * 4 + (32 + 9 * 4) + (32 + 5 * 4) + (32 + 1 * 4)
+    want = 3 * 64 + 2 * (2 * W + 2 * A) + 4 + 8 + 3 * 64 + 84 * per_q + 32 + 1 + 12
+    assert oracle.orc_g1_proof_len(16) == want

@@ -1,0 +1,195 @@
+"""CPU tests: the oracle against golden vectors and algebraic identities (no GPU needed)."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from plonky2_bn254_amd import synth
+from tests import oracle_lib
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+P = 2**64 - 2**32 + 1
+Q = synth.P
+
+
+def words(v, n=4):
+    return np.array([(v >> (64 * i)) & synth.MASK64 for i in range(n)], dtype=np.uint64)
+
+
+def test_poseidon_kats(oracle):
+    kat = json.load(open(os.path.join(GOLD, "poseidon_kat.json")))
+    inputs = {"zeros": [0] * 12, "range12": list(range(12)), "neg_ones": [P - 1] * 12}
+    for k in kat["kats"]:
+        st = np.array(inputs[k["input"]], dtype=np.uint64)
+        oracle.orc_poseidon_permute(oracle_lib.ptr(st))
+        assert " ".join("%016x" % int(v) for v in st) == k["output"]
+    for fn in ("oracle/poseidon_constants.inc", "plonky2_bn254_amd/csrc/poseidon_constants.inc"):
+        txt = open(os.path.join(os.path.dirname(GOLD), "..", fn)).read()
+        consts = [int(t.rstrip("ULL,"), 16) for t in txt.split() if t.startswith("0x")]
+        assert len(consts) == 360
+        digest = hashlib.sha256(b"".join(int(c).to_bytes(8, "little") for c in consts)).hexdigest()
+        assert digest == kat["round_constants_sha256_le_u64"], fn
+
+
+def test_goldilocks_field_ops(oracle):
+    rng = np.random.default_rng(3)
+    for _ in range(200):
+        a, b = int(rng.integers(0, 2**63)) * 2 % P, int(rng.integers(0, 2**63)) % P
+        assert oracle.orc_gl_mul(a, b) == a * b % P
+    for a in (1, 2, P - 1, 0xc65c18b67785d900, 12345678901234567):
+        assert oracle.orc_gl_inv(a) == pow(a, -1, P)
+
+
+def test_bn254_golden_vectors(oracle):
+    vec = json.load(open(os.path.join(GOLD, "bn254_kat.json")))
+    out = np.zeros(4, np.uint64)
+    for a, b, c in vec["fq_mul"]:
+        oracle.orc_fq_mul(oracle_lib.ptr(words(int(a))), oracle_lib.ptr(words(int(b))), oracle_lib.ptr(out))
+        assert synth.words_to_int(out) == int(c)
+    for a, ai in vec["fq_inv"]:
+        oracle.orc_fq_inv(oracle_lib.ptr(words(int(a))), oracle_lib.ptr(out))
+        assert synth.words_to_int(out) == int(ai)
+    out8 = np.zeros(8, np.uint64)
+    for a, b, c in vec["g1_add"]:
+        pa = np.concatenate([words(int(a[0])), words(int(a[1]))])
+        pb = np.concatenate([words(int(b[0])), words(int(b[1]))])
+        assert oracle.orc_g1_add(oracle_lib.ptr(pa), oracle_lib.ptr(pb), oracle_lib.ptr(out8)) == 0
+        assert (synth.words_to_int(out8[:4]), synth.words_to_int(out8[4:])) == (int(c[0]), int(c[1]))
+
+
+@pytest.mark.parametrize("n", [1, 2, 8, 64])
+def test_ntt_against_naive_dft(oracle, n):
+    rng = np.random.default_rng(n)
+    c = [int(v) % P for v in rng.integers(0, 2**63, size=n)]
+    w = pow(0x64fdd1a46201e246, 2 ** (32 - (n.bit_length() - 1)), P)   # primitive n-th root
+    want = [sum(c[i] * pow(w, i * j, P) for i in range(n)) % P for j in range(n)]
+    a = np.array(c, dtype=np.uint64)
+    oracle.orc_ntt(oracle_lib.ptr(a), n, 0, 0)
+    assert [int(v) for v in a] == want
+    oracle.orc_ntt(oracle_lib.ptr(a), n, 1, 0)          # ifft(fft(c)) == c
+    assert [int(v) for v in a] == c
+    shift = 0xc65c18b67785d900
+    b = np.array(c, dtype=np.uint64)
+    oracle.orc_ntt(oracle_lib.ptr(b), n, 2, shift)      # coset fft = evaluation at shift * w^j
+    assert [int(v) for v in b] == [sum(c[i] * pow(shift * pow(w, j, P), i, P) for i in range(n)) % P for j in range(n)]
+    oracle.orc_ntt(oracle_lib.ptr(b), n, 3, shift)
+    assert [int(v) for v in b] == c
+
+
+def test_merkle_cap_and_hash_or_noop(oracle):
+    # leaves of <= 4 elements are not hashed (hash_or_noop); cap of a 32-leaf tree = 16 two_to_one nodes
+    leaves = np.arange(32 * 3, dtype=np.uint64).reshape(32, 3)
+    cap = np.zeros((16, 4), np.uint64)
+    oracle.orc_merkle_cap(oracle_lib.ptr(leaves), 32, 3, 4, oracle_lib.ptr(cap))
+    for i in range(16):
+        l = np.array(list(leaves[2 * i]) + [0], dtype=np.uint64)
+        r = np.array(list(leaves[2 * i + 1]) + [0], dtype=np.uint64)
+        st = np.concatenate([l, r, np.zeros(4, np.uint64)])
+        oracle.orc_poseidon_permute(oracle_lib.ptr(st))
+        assert np.array_equal(cap[i], st[:4])
+    # hash_no_pad: overwrite-mode sponge over 8-element chunks, last chunk keeps the old rate lanes
+    x = np.arange(1, 12, dtype=np.uint64)
+    d = np.zeros(4, np.uint64)
+    oracle.orc_hash_or_noop(oracle_lib.ptr(x), 11, oracle_lib.ptr(d))
+    st = np.zeros(12, np.uint64)
+    st[:8] = x[:8]
+    oracle.orc_poseidon_permute(oracle_lib.ptr(st))
+    st[:3] = x[8:]
+    oracle.orc_poseidon_permute(oracle_lib.ptr(st))
+    assert np.array_equal(d, st[:4])
+
+
+def test_challenger_pop_order(oracle):
+    # 8 observations trigger one duplexing; challenges pop from lane 7 downwards
+    obs = np.arange(10, 18, dtype=np.uint64)
+    out = np.zeros(3, np.uint64)
+    oracle.orc_challenger_observe_get(oracle_lib.ptr(obs), 8, oracle_lib.ptr(out), 3)
+    st = np.zeros(12, np.uint64)
+    st[:8] = obs
+    oracle.orc_poseidon_permute(oracle_lib.ptr(st))
+    assert [int(v) for v in out] == [int(st[7]), int(st[6]), int(st[5])]
+
+
+def test_modulus_zero_identity(oracle):
+    """generate_modulus_zero output satisfies assert_modulus_zero (modulus_zero.rs:126-160) over the integers."""
+    rng = synth.Xoshiro256ss(5)
+    mod_limbs = [(Q >> (16 * i)) & 0xFFFF for i in range(16)]
+    for case in range(10):
+        a, b = rng.next_u256() % Q, rng.next_u256() % Q
+        c = a * b % Q
+        al = [(a >> (16 * i)) & 0xFFFF for i in range(16)]
+        bl = [(b >> (16 * i)) & 0xFFFF for i in range(16)]
+        cl = [(c >> (16 * i)) & 0xFFFF for i in range(16)]
+        diff = [0] * 31
+        for i in range(16):
+            for j in range(16):
+                diff[i + j] += al[i] * bl[j]
+        for i in range(16):
+            diff[i] -= cl[i]
+        if case % 2:   # negative quotient as well
+            diff = [-d for d in diff]
+        inp = np.array(diff, dtype=np.int64)
+        out = np.zeros(80, np.uint64)
+        assert oracle.orc_generate_modulus_zero(oracle_lib.ptr(inp), oracle_lib.ptr(out)) == 0
+        iqp, quot_abs = int(out[0]), [int(v) for v in out[1:18]]
+        lo, hi = [int(v) for v in out[18:49]], [int(v) for v in out[49:80]]
+        assert all(v < 65536 for v in quot_abs + lo + hi)
+        sign = 2 * iqp - 1
+        constr = [0] * 32
+        for i in range(17):
+            for j in range(16):
+                constr[i + j] += sign * quot_abs[i] * mod_limbs[j]
+        aux = [lo[i] - (1 << 29) + (hi[i] << 16) for i in range(31)] + [0]
+        constr[0] += -(1 << 16) * aux[0]
+        for d in range(1, 32):
+            constr[d] += aux[d - 1] - (1 << 16) * aux[d]
+        for i in range(31):
+            constr[i] -= diff[i]
+        assert constr == [0] * 32
+        total = sum(d << (16 * i) for i, d in enumerate(diff))
+        assert total % Q == 0 and (iqp == 1) == (total > 0)
+    bad = np.zeros(31, np.int64)
+    bad[0] = 1   # not a multiple of p: the reference asserts (modulus_zero.rs:82)
+    assert oracle.orc_generate_modulus_zero(oracle_lib.ptr(bad), oracle_lib.ptr(np.zeros(80, np.uint64))) == -1
+
+
+def test_g1_trace_satisfies_air_and_layout(oracle):
+    """Every transition of a generated trace satisfies the 1111 constraints; column map as in
+    scalar_mul_view.rs (row_position_correctness: INPUT_FILTER 770, OUTPUT_FILTER 771, TIMESTAMP 775,
+    FREQ 779, RANGE_COUNTER 780)."""
+    assert oracle.orc_g1_width() == 781
+    s, x, o = synth.g1_inputs(2, seed=3)
+    o[1] = x[1]   # doubling branch on an addition row
+    rows = oracle.orc_g1_num_rows(2, 16)
+    tr = np.zeros((781, rows), np.uint64)
+    outs = np.zeros((2, 8), np.uint64)
+    assert oracle.orc_g1_generate_trace(oracle_lib.ptr(s), oracle_lib.ptr(x), oracle_lib.ptr(o), 2, 16, oracle_lib.ptr(tr),
+                                        oracle_lib.ptr(outs)) == 0
+    assert tr[770, 0] == 1 and tr[770, 512] == 1 and tr[770, 1:512].sum() == 0
+    assert tr[771, 511] == 1 and tr[771, 1023] == 1 and tr[771, :511].sum() == 0
+    assert (tr[775, :512] == 0).all() and (tr[775, 512:1024] == 1).all()
+    assert (tr[780, :65536] == np.arange(65536)).all()
+    assert int(tr[779].sum()) == 450 * rows        # every range-checked cell counted once
+    assert (tr[64:514] < 65536).all()
+    alphas = np.array([0x1234567887654321 % P, 0x0fedcba998765432 % P], dtype=np.uint64)
+    accs = np.zeros(2, np.uint64)
+    rowsT = np.ascontiguousarray(tr.T)
+    for r in list(range(0, 8)) + [510, 511, 512, 513, 1022, 1023, 1024, 40000]:
+        loc, nxt = rowsT[r], rowsT[(r + 1) % rows]
+        # z_last / lagrange selectors for a non-last, non-first row of the subgroup: the transition factor is
+        # non-zero, first/last-row selectors vanish
+        n = oracle.orc_g1_eval_constraints(oracle_lib.ptr(loc), oracle_lib.ptr(nxt), oracle_lib.ptr(alphas), 7, 0, 0,
+                                           oracle_lib.ptr(accs))
+        assert n == 1111
+        assert accs[0] == 0 and accs[1] == 0, f"row {r}"
+    # a corrupted cell must break it
+    loc = rowsT[3].copy()
+    loc[130] ^= np.uint64(1)
+    oracle.orc_g1_eval_constraints(oracle_lib.ptr(loc), oracle_lib.ptr(rowsT[4]), oracle_lib.ptr(alphas), 7, 0, 0, oracle_lib.ptr(accs))
+    assert accs[0] != 0
+    for i in range(2):
+        exp = synth.g1_scalar_mul_offset(synth.words_to_int(s[i]), (synth.words_to_int(x[i, :4]), synth.words_to_int(x[i, 4:])),
+                                         (synth.words_to_int(o[i, :4]), synth.words_to_int(o[i, 4:])))
+        assert (synth.words_to_int(outs[i, :4]), synth.words_to_int(outs[i, 4:])) == exp
