@@ -91,11 +91,12 @@ int bn254s_prove_g1(bn254s_ctx* ctx, const bn254s_params* params, const uint64_t
 int bn254s_prove_g1_batch(bn254s_ctx* ctx, const bn254s_params* params, const uint64_t* scalars, const uint64_t* x,
                           const uint64_t* offset, size_t n_total, size_t per_proof, bn254s_proof** proofs_out);
 
-/* Same for G2 (points n x 16) and Fq exponentiation x^s (x n x 4): src/generators/{g2,fq}/stark_proof.rs. */
+/* Same for G2 (points n x 16 words: x.c0, x.c1, y.c0, y.c1): src/generators/g2/stark_proof.rs:136-179. */
 int bn254s_prove_g2(bn254s_ctx* ctx, const bn254s_params* params, const uint64_t* scalars, const uint64_t* x,
                     const uint64_t* offset, size_t n, bn254s_proof** out);
-int bn254s_prove_fq_exp(bn254s_ctx* ctx, const bn254s_params* params, const uint64_t* scalars, const uint64_t* x,
-                        const uint64_t* offset /* n x 4 */, size_t n, bn254s_proof** out);
+/* Fq exponentiation x_i ^ s_i (FqExpInput { s, x }, src/starks/fields/exp_stark.rs:36-39): no offset. */
+int bn254s_prove_fq_exp(bn254s_ctx* ctx, const bn254s_params* params, const uint64_t* scalars /* n x 4 */,
+                        const uint64_t* x /* n x 4 */, size_t n, bn254s_proof** out);
 
 /* Proof accessors.  Pointers stay valid until bn254s_proof_free. */
 int bn254s_proof_words(const bn254s_proof* p, const uint64_t** data, size_t* len);
@@ -118,7 +119,10 @@ int bn254s_commit_values(bn254s_ctx* ctx, const uint64_t* values, size_t ncols, 
 int bn254s_bench_ntt(bn254s_ctx* ctx, size_t ncols, int iters, float* ms);
 /* Poseidon permutation of `n` 12-word states in place (host buffer). */
 int bn254s_poseidon_permute(bn254s_ctx* ctx, uint64_t* states, size_t n);
-/* Trace generation only: column-major trace[W][rows] copied to the host buffer. */
+/* Trace generation only: column-major trace[W][rows] copied to the host buffer.
+ * kind: 0 = G1 scalar mul (W 781), 1 = G2 scalar mul (W 1295), 2 = Fq exp (W 427; offset ignored). */
+int bn254s_generate_trace(bn254s_ctx* ctx, int kind, const uint64_t* scalars, const uint64_t* x, const uint64_t* offset,
+                          size_t n, uint32_t min_rows_log2, uint64_t* trace_out, uint64_t* outputs);
 int bn254s_g1_generate_trace(bn254s_ctx* ctx, const uint64_t* scalars, const uint64_t* x, const uint64_t* offset,
                              size_t n, uint32_t min_rows_log2, uint64_t* trace_out, uint64_t* outputs);
 

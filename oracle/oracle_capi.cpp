@@ -2,6 +2,7 @@
 // cpu_baseline leg of bench.py (loaded with ctypes as oracle/liboracle.so).  Nothing in
 // plonky2_bn254_amd/ may link or load this library.
 #include "g1_stark.hpp"
+#include "g2_fq_stark.hpp"
 #include <chrono>
 #include <cstdio>
 #include <cstring>
@@ -277,6 +278,156 @@ int orc_g1_verify(const u64* proof, size_t proof_len, int degree_bits, const u64
   } catch (std::exception& e) {
     return fail(e);
   }
+}
+
+
+// ---- generic entry points: kind 0 = G1 scalar mul, 1 = G2 scalar mul, 2 = Fq exponentiation ---------------
+// inputs: scalars n x 4; x n x {8,16,4}; off n x {8,16} (ignored for kind 2); outputs n x {8,16,4}.
+static int point_words(int kind) { return kind == 0 ? 8 : kind == 1 ? 16 : 4; }
+static StarkDef def_of(int kind) { return kind == 0 ? g1::stark_def() : kind == 1 ? g2::stark_def() : fqexp::stark_def(); }
+
+struct GenOut {
+  std::vector<std::vector<u64>> trace;
+  std::vector<u64> outputs;                            // n x point_words
+  std::vector<std::vector<std::vector<u64>>> ctl;      // extra looking values
+};
+static void put_u256(std::vector<u64>& v, const U256& x) { v.insert(v.end(), x.l, x.l + 4); }
+
+static GenOut run_kind(int kind, const u64* scalars, const u64* x, const u64* off, size_t n, int min_rows_log2, bool want_trace) {
+  GenOut o;
+  size_t min_rows = (size_t)1 << min_rows_log2;
+  if (kind == 0) {
+    auto in = unpack_g1(scalars, x, off, n);
+    std::vector<g1::Affine> outs(n);
+    if (want_trace) o.trace = g1::generate_trace(in, min_rows, &outs);
+    else {
+#pragma omp parallel for schedule(dynamic, 1)
+      for (size_t k = 0; k < n; k++) outs[k] = g1::scalar_mul_offset(in[k]);
+    }
+    for (auto& p : outs) { put_u256(o.outputs, fq_to_u256(p.x)); put_u256(o.outputs, fq_to_u256(p.y)); }
+    o.ctl = g1::generate_ctl_values(in, outs);
+  } else if (kind == 1) {
+    std::vector<g2::Input> in(n);
+    for (size_t k = 0; k < n; k++) {
+      memcpy(in[k].s, scalars + 4 * k, 32);
+      for (int j = 0; j < 4; j++) {
+        memcpy(in[k].x[j].l, x + 16 * k + 4 * j, 32);
+        memcpy(in[k].off[j].l, off + 16 * k + 4 * j, 32);
+      }
+    }
+    std::vector<g2::Affine> outs(n);
+    if (want_trace) o.trace = g2::generate_trace(in, min_rows, &outs);
+    else {
+#pragma omp parallel for schedule(dynamic, 1)
+      for (size_t k = 0; k < n; k++) outs[k] = g2::scalar_mul_offset(in[k]);
+    }
+    for (auto& p : outs) {
+      put_u256(o.outputs, fq_to_u256(p.x.c0)); put_u256(o.outputs, fq_to_u256(p.x.c1));
+      put_u256(o.outputs, fq_to_u256(p.y.c0)); put_u256(o.outputs, fq_to_u256(p.y.c1));
+    }
+    o.ctl = g2::generate_ctl_values(in, outs);
+  } else {
+    std::vector<fqexp::Input> in(n);
+    for (size_t k = 0; k < n; k++) {
+      memcpy(in[k].s, scalars + 4 * k, 32);
+      memcpy(in[k].x.l, x + 4 * k, 32);
+    }
+    std::vector<Fq> outs(n);
+    if (want_trace) o.trace = fqexp::generate_trace(in, min_rows, &outs);
+    else {
+#pragma omp parallel for schedule(dynamic, 1)
+      for (size_t k = 0; k < n; k++) outs[k] = fqexp::pow_s(in[k]);
+    }
+    for (auto& p : outs) put_u256(o.outputs, fq_to_u256(p));
+    o.ctl = fqexp::generate_ctl_values(in, outs);
+  }
+  return o;
+}
+
+int orc_stark_width(int kind) { return def_of(kind).W; }
+size_t orc_proof_len(int kind, int degree_bits) {
+  StarkDef d = def_of(kind);
+  StarkConfig cfg;
+  int A = 2 * (d.num_helpers() + 1) + 4, nq = 4, capn = 16;
+  std::vector<int> ar = cfg.fri_arities(degree_bits);
+  int lde_bits = degree_bits + 1;
+  size_t len = 3 * capn * 4 + 2 * (2 * d.W + 2 * A) + 4 + 2 * nq + ar.size() * capn * 4;
+  size_t per_q = (d.W + A + nq) + 3 * 4 * (lde_bits - 4);
+  int bits = lde_bits, sum = 0;
+  for (int a : ar) {
+    bits -= a;
+    sum += a;
+    per_q += 2 * (1 << a) + 4 * (bits - 4);
+  }
+  len += 84 * per_q + 2 * ((size_t)1 << (degree_bits - sum)) + 1 + 12;
+  return len;
+}
+int orc_generate_trace(int kind, const u64* scalars, const u64* x, const u64* off, size_t n, int min_rows_log2, u64* trace_out,
+                       u64* outputs) {
+  try {
+    GenOut g = run_kind(kind, scalars, x, off, n, min_rows_log2, true);
+    size_t rows = g.trace[0].size();
+    for (size_t c = 0; c < g.trace.size(); c++) memcpy(trace_out + c * rows, g.trace[c].data(), 8 * rows);
+    if (outputs) memcpy(outputs, g.outputs.data(), 8 * g.outputs.size());
+    return 0;
+  } catch (std::exception& e) {
+    return fail(e);
+  }
+}
+int orc_prove(int kind, const u64* scalars, const u64* x, const u64* off, size_t n, int min_rows_log2, u64* proof_out,
+              size_t proof_cap, u64* outputs, double* timings) {
+  try {
+    double t0 = now_sec();
+    GenOut g = run_kind(kind, scalars, x, off, n, min_rows_log2, true);
+    double t1 = now_sec();
+    StarkDef d = def_of(kind);
+    StarkConfig cfg;
+    ProveTimings tm;
+    Proof pr = prove(d, cfg, g.trace, &tm);
+    std::vector<u64> flat = pr.serialize();
+    if (flat.size() > proof_cap) throw std::runtime_error("proof buffer too small");
+    memcpy(proof_out, flat.data(), 8 * flat.size());
+    if (outputs) memcpy(outputs, g.outputs.data(), 8 * g.outputs.size());
+    if (timings) {
+      double t[8] = {t1 - t0, tm.trace_commit, tm.aux, tm.aux_commit, tm.quotient, tm.quotient_commit, tm.openings, tm.fri};
+      memcpy(timings, t, sizeof(t));
+    }
+    return (int)flat.size();
+  } catch (std::exception& e) {
+    return fail(e);
+  }
+}
+int orc_verify(int kind, const u64* proof, size_t proof_len, int degree_bits, const u64* scalars, const u64* x, const u64* off,
+               size_t n) {
+  try {
+    StarkDef d = def_of(kind);
+    StarkConfig cfg;
+    Proof pr = deserialize_proof(d, cfg, degree_bits, proof, proof_len);
+    GenOut g = run_kind(kind, scalars, x, off, n, 16, false);
+    std::string r = verify(d, cfg, pr, g.ctl);
+    if (!r.empty()) {
+      snprintf(g_err, sizeof(g_err), "%s", r.c_str());
+      return 1;
+    }
+    return 0;
+  } catch (std::exception& e) {
+    return fail(e);
+  }
+}
+// constraints of one (local, next) pair: returns the number emitted, accs2 = the two alpha accumulators
+int orc_eval_constraints(int kind, const u64* local, const u64* next, const u64* alphas2, u64 z_last, u64 lfirst, u64 llast,
+                         u64* accs2) {
+  StarkDef d = def_of(kind);
+  std::vector<F> l(d.W), nx(d.W);
+  for (int i = 0; i < d.W; i++) {
+    l[i] = F(local[i]);
+    nx[i] = F(next[i]);
+  }
+  Consumer<F> cc({F(alphas2[0]), F(alphas2[1])}, F(z_last), F(lfirst), F(llast));
+  d.eval_base(l.data(), nx.data(), cc);
+  accs2[0] = cc.accs[0].v;
+  accs2[1] = cc.accs[1].v;
+  return (int)cc.count;
 }
 
 }  // extern "C"

@@ -182,3 +182,90 @@ __device__ __forceinline__ int g1_add(const g1j& p, const g1j& q, g1j& r) {
   r.z = fq_mul(fq_mul(p.z, q.z), h);
   return 0;
 }
+
+// ---- Fq2 = Fq[u]/(u^2+1) and G2 (y^2 = x^3 + b2), Jacobian ------------------------------------------------
+// Replaces ark-bn254 Fq2 / G2Affine at reference src/starks/curves/g2/add.rs:59-130.
+struct fq2 {
+  fq c0, c1;
+};
+__device__ __forceinline__ fq2 fq2_zero() {
+  fq2 r;
+  r.c0 = fq_zero();
+  r.c1 = fq_zero();
+  return r;
+}
+__device__ __forceinline__ fq2 fq2_one() {
+  fq2 r;
+  r.c0 = fq_one();
+  r.c1 = fq_zero();
+  return r;
+}
+__device__ __forceinline__ bool fq2_is_zero(const fq2& a) { return fq_is_zero(a.c0) && fq_is_zero(a.c1); }
+__device__ __forceinline__ bool fq2_eq(const fq2& a, const fq2& b) { return fq_eq(a.c0, b.c0) && fq_eq(a.c1, b.c1); }
+__device__ __forceinline__ fq2 fq2_add(const fq2& a, const fq2& b) {
+  fq2 r;
+  r.c0 = fq_add(a.c0, b.c0);
+  r.c1 = fq_add(a.c1, b.c1);
+  return r;
+}
+__device__ __forceinline__ fq2 fq2_sub(const fq2& a, const fq2& b) {
+  fq2 r;
+  r.c0 = fq_sub(a.c0, b.c0);
+  r.c1 = fq_sub(a.c1, b.c1);
+  return r;
+}
+__device__ __forceinline__ fq2 fq2_dbl(const fq2& a) { return fq2_add(a, a); }
+__device__ __noinline__ fq2 fq2_mul(const fq2& a, const fq2& b) {  // Karatsuba: 3 Fq products
+  fq t0 = fq_mul(a.c0, b.c0), t1 = fq_mul(a.c1, b.c1);
+  fq t2 = fq_mul(fq_add(a.c0, a.c1), fq_add(b.c0, b.c1));
+  fq2 r;
+  r.c0 = fq_sub(t0, t1);
+  r.c1 = fq_sub(fq_sub(t2, t0), t1);
+  return r;
+}
+__device__ __forceinline__ fq2 fq2_sqr(const fq2& a) { return fq2_mul(a, a); }
+__device__ __forceinline__ fq fq2_norm(const fq2& a) { return fq_add(fq_sqr(a.c0), fq_sqr(a.c1)); }
+// a^-1 given n^-1 with n = norm(a)
+__device__ __forceinline__ fq2 fq2_inv_from_norm_inv(const fq2& a, const fq& ninv) {
+  fq2 r;
+  r.c0 = fq_mul(a.c0, ninv);
+  r.c1 = fq_neg(fq_mul(a.c1, ninv));
+  return r;
+}
+
+struct g2j {
+  fq2 x, y, z;
+};
+__device__ __forceinline__ g2j g2_double(const g2j& p) {
+  fq2 a = fq2_sqr(p.x), b = fq2_sqr(p.y), c = fq2_sqr(b);
+  fq2 xb = fq2_add(p.x, b);
+  fq2 d = fq2_dbl(fq2_sub(fq2_sub(fq2_sqr(xb), a), c));
+  fq2 e = fq2_add(fq2_dbl(a), a);
+  fq2 f = fq2_sqr(e);
+  g2j r;
+  r.x = fq2_sub(f, fq2_dbl(d));
+  fq2 c8 = fq2_dbl(fq2_dbl(fq2_dbl(c)));
+  r.y = fq2_sub(fq2_mul(e, fq2_sub(d, r.x)), c8);
+  r.z = fq2_dbl(fq2_mul(p.y, p.z));
+  return r;
+}
+// 0 ok, 1 equal points (doubled), 2 opposite points (infinity)
+__device__ __forceinline__ int g2_add(const g2j& p, const g2j& q, g2j& r) {
+  fq2 z1z1 = fq2_sqr(p.z), z2z2 = fq2_sqr(q.z);
+  fq2 u1 = fq2_mul(p.x, z2z2), u2 = fq2_mul(q.x, z1z1);
+  fq2 s1 = fq2_mul(fq2_mul(p.y, q.z), z2z2), s2 = fq2_mul(fq2_mul(q.y, p.z), z1z1);
+  fq2 h = fq2_sub(u2, u1), rr = fq2_sub(s2, s1);
+  if (fq2_is_zero(h)) {
+    if (fq2_is_zero(rr)) {
+      r = g2_double(p);
+      return 1;
+    }
+    r = p;
+    return 2;
+  }
+  fq2 hh = fq2_sqr(h), hhh = fq2_mul(h, hh), v = fq2_mul(u1, hh);
+  r.x = fq2_sub(fq2_sub(fq2_sqr(rr), hhh), fq2_dbl(v));
+  r.y = fq2_sub(fq2_mul(rr, fq2_sub(v, r.x)), fq2_mul(s1, hhh));
+  r.z = fq2_mul(fq2_mul(p.z, q.z), h);
+  return 0;
+}

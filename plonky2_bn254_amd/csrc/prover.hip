@@ -9,6 +9,7 @@
 #include <thread>
 #include "ctx.h"
 #include "trace_g1.h"
+#include "trace_g2fq.h"
 #include "aux.h"
 #include "merkle.h"
 #include "quotient.h"
@@ -16,30 +17,39 @@
 #include "transcript.h"
 
 // ---- shapes -------------------------------------------------------------------------------------------------
-StarkShape g1_shape() {  // scalar_mul_view.rs:10-30, scalar_mul_stark.rs:493-500, scalar_mul_ctl.rs:20-55
+// Stark::lookups (range-checked columns), the two looked CTL tables and the constraint counts of the three AIRs:
+// G1 scalar_mul_{view,stark,ctl}.rs, G2 twins, fields/exp_{view,stark,ctl}.rs.
+template <class L>
+static StarkShape make_shape(bool input_has_a, int n_constraints) {
   StarkShape s;
-  s.W = G1_W;
-  s.rc_begin = G1_RC_BEGIN;
-  s.rc_end = G1_RC_END;
-  s.table_col = G1_COL_RANGE;
-  s.freq_col = G1_COL_FREQ;
+  s.W = L::W;
+  s.rc_begin = L::RC_BEGIN;
+  s.rc_end = L::RC_END;
+  s.table_col = L::RANGE;
+  s.freq_col = L::FREQ;
   s.n_ctl = 2;
-  s.n_constraints = 1111;
+  s.n_constraints = n_constraints;
   memset(&s.ctl, 0, sizeof(s.ctl));
   int m = 0;
-  for (int i = 0; i < 32; i++, m++) { s.ctl.col_start[0][m] = G1_COL_B + i; s.ctl.col_bits[0][m] = 1; }
-  for (int i = 0; i < 32; i++, m++) { s.ctl.col_start[0][m] = G1_COL_A + i; s.ctl.col_bits[0][m] = 1; }
-  for (int k = 0; k < 16; k++, m++) { s.ctl.col_start[0][m] = G1_COL_BITS + 16 * k; s.ctl.col_bits[0][m] = 16; }
-  s.ctl.col_start[0][m] = G1_COL_TIMESTAMP; s.ctl.col_bits[0][m] = 1; m++;
+  for (int i = 0; i < L::PL; i++, m++) { s.ctl.col_start[0][m] = L::B + i; s.ctl.col_bits[0][m] = 1; }
+  if (input_has_a)
+    for (int i = 0; i < L::PL; i++, m++) { s.ctl.col_start[0][m] = L::A + i; s.ctl.col_bits[0][m] = 1; }
+  for (int k = 0; k < 16; k++, m++) { s.ctl.col_start[0][m] = L::BITS + 16 * k; s.ctl.col_bits[0][m] = 16; }
+  s.ctl.col_start[0][m] = L::TIMESTAMP; s.ctl.col_bits[0][m] = 1; m++;
   s.ctl.ncols[0] = m;
-  s.ctl.filter_col[0] = G1_COL_FLAGS + 0;
+  s.ctl.filter_col[0] = L::FLAGS + 0;
   m = 0;
-  for (int i = 0; i < 32; i++, m++) { s.ctl.col_start[1][m] = G1_COL_SUM + i; s.ctl.col_bits[1][m] = 1; }
-  s.ctl.col_start[1][m] = G1_COL_TIMESTAMP; s.ctl.col_bits[1][m] = 1; m++;
+  for (int i = 0; i < L::PL; i++, m++) { s.ctl.col_start[1][m] = L::SUM + i; s.ctl.col_bits[1][m] = 1; }
+  s.ctl.col_start[1][m] = L::TIMESTAMP; s.ctl.col_bits[1][m] = 1; m++;
   s.ctl.ncols[1] = m;
-  s.ctl.filter_col[1] = G1_COL_FLAGS + 1;
+  s.ctl.filter_col[1] = L::FLAGS + 1;
   return s;
 }
+StarkShape g1_shape() { return make_shape<G1L>(true, 1111); }
+static StarkShape shape_for(int kind) {
+  return kind == KIND_G1 ? make_shape<G1L>(true, 1111) : kind == KIND_G2 ? make_shape<G2L>(true, 1693) : make_shape<FQL>(false, 770);
+}
+static int point_words(int kind) { return kind == KIND_G1 ? 8 : kind == KIND_G2 ? 16 : 4; }
 
 // ---- proof object ---------------------------------------------------------------------------------------------
 enum { ST_TRACE = 0, ST_TRACE_NTT, ST_TRACE_MERKLE, ST_AUX, ST_AUX_NTT, ST_AUX_MERKLE, ST_QUOTIENT, ST_QUOTIENT_COMMIT,
@@ -117,12 +127,13 @@ static int get_point_tables(bn254s_ctx* c, unsigned log_n, QPointTables& pt) {
   return 0;
 }
 
-static int prove_g1_on_slot(bn254s_ctx* c, Slot& sl, const bn254s_params& P, const u64* scalars, const u64* x, const u64* off,
-                            size_t n, bn254s_proof* pr, std::string& err) {
-  const StarkShape sh = g1_shape();
+static int prove_on_slot(bn254s_ctx* c, Slot& sl, int kind, const bn254s_params& P, const u64* scalars, const u64* x,
+                         const u64* off, size_t n, bn254s_proof* pr, std::string& err) {
+  const StarkShape sh = shape_for(kind);
+  const int PW = point_words(kind);
   const size_t N = rows_for(n, P.min_rows_log2);
   if (N != NTT_N) {
-    err = "this build proves 2^16-row traces only (<= 128 instances per proof); use bn254s_prove_g1_batch";
+    err = "this build proves 2^16-row traces only (<= 128 instances per proof); cut larger batches into several proofs";
     return BN254S_E_UNSUPPORTED;
   }
   if (P.num_challenges != 2 || P.rate_bits != 1 || P.cap_height != 4 || P.arity_bits != 4 || P.min_rows_log2 < 16 ||
@@ -146,7 +157,8 @@ static int prove_g1_on_slot(bn254s_ctx* c, Slot& sl, const bn254s_params& P, con
   if (L > FRI_MAX_LAYERS) return BN254S_E_UNSUPPORTED;
 
   // ---- workspace ------------------------------------------------------------------------------------------
-  u64* d_in = mem.words("in", n * 20 + 16);
+  const size_t in_words = n * (4 + 2 * (size_t)PW);
+  u64* d_in = mem.words("in", in_words + 16);
   u64* d_tvals = mem.words("tvals", (size_t)W * N);
   u64* d_tcoef = mem.words("tcoef", (size_t)W * N);
   u64* d_tmp = mem.words("tmp", (size_t)std::max(W, A) * N);
@@ -156,9 +168,10 @@ static int prove_g1_on_slot(bn254s_ctx* c, Slot& sl, const bn254s_params& P, con
   u64* d_avals = mem.words("avals", (size_t)A * N);
   u64* d_acoef = mem.words("acoef", (size_t)A * N);
   u64* d_alde = mem.words("alde", (size_t)A * M2);
-  u64* d_scr = mem.words("scratch", std::max(g1_trace_scratch_words(n), aux_scratch_words(sh, N)));
+  const size_t trace_scr = kind == KIND_G1 ? g1_trace_scratch_words(n) : kind == KIND_G2 ? g2_trace_scratch_words(n) : fq_trace_scratch_words(n);
+  u64* d_scr = mem.words("scratch", std::max(trace_scr, aux_scratch_words(sh, N)));
   u64* d_q = mem.words("quot", (size_t)(3 * NQ) * N + (size_t)NQ * M2);  // qv, ab, qcoef, qlde
-  u64* d_tabs = mem.words("tabs", 2 * (size_t)K + 5 * 2 * 80 + 2 * (size_t)(W + A + NQ));
+  u64* d_tabs = mem.words("tabs", 2 * (size_t)K + 10 * 2 * 80 + 2 * (size_t)(W + A + NQ));
   u64* d_open = mem.words("open", (size_t)(W + A + NQ) * 5);
   // FRI layer values (extension, 2 words) and trees
   size_t fri_words = 0, fri_tree_words = 0;
@@ -187,8 +200,8 @@ static int prove_g1_on_slot(bn254s_ctx* c, Slot& sl, const bn254s_params& P, con
     err = mem.err;
     return BN254S_E_OOM;
   }
-  int* d_err = (int*)(d_in + n * 20);
-  unsigned long long* d_pow = (unsigned long long*)(d_in + n * 20 + 2);
+  int* d_err = (int*)(d_in + in_words);
+  unsigned long long* d_pow = (unsigned long long*)(d_in + in_words + 2);
   u32* d_qidx = (u32*)(d_qout + wpq * P.num_queries);
   u64* d_ttree = d_trees;
   u64* d_atree = d_trees + tree_words;
@@ -199,7 +212,7 @@ static int prove_g1_on_slot(bn254s_ctx* c, Slot& sl, const bn254s_params& P, con
   u64* d_qlde = d_q + (size_t)3 * NQ * N;   // [4][2N]
   u64* d_W = d_tabs;
   u64* d_mzt = d_tabs + 2 * (size_t)K;
-  u64* d_apow = d_mzt + 5 * 2 * 80;
+  u64* d_apow = d_mzt + 10 * 2 * 80;
   const size_t cap_off = 4 * merkle_level_offset(log_m2, log_m2 - P.cap_height);
 
   hipEvent_t ev[2 * ST_COUNT];
@@ -215,17 +228,23 @@ static int prove_g1_on_slot(bn254s_ctx* c, Slot& sl, const bn254s_params& P, con
   sb(ST_TOTAL);
   sb(ST_TRACE);
   CHK(hipMemsetAsync(d_err, 0, 16, st));
-  CHK(hipMemcpyAsync(d_in, scalars, n * 32, hipMemcpyHostToDevice, st));
-  CHK(hipMemcpyAsync(d_in + 4 * n, x, n * 64, hipMemcpyHostToDevice, st));
-  CHK(hipMemcpyAsync(d_in + 12 * n, off, n * 64, hipMemcpyHostToDevice, st));
-  u64* d_outs = d_open;  // n*8 words fit (reused later)
-  if (g1_generate_trace_device(d_in, d_in + 4 * n, d_in + 12 * n, n, d_tvals, N, d_scr, d_outs, d_err, st)) {
+  u64* d_sc = d_in;
+  u64* d_x = d_in + 4 * n;
+  u64* d_off = d_x + (size_t)PW * n;
+  CHK(hipMemcpyAsync(d_sc, scalars, n * 32, hipMemcpyHostToDevice, st));
+  CHK(hipMemcpyAsync(d_x, x, n * (size_t)PW * 8, hipMemcpyHostToDevice, st));
+  if (kind != KIND_FQ) CHK(hipMemcpyAsync(d_off, off, n * (size_t)PW * 8, hipMemcpyHostToDevice, st));
+  u64* d_outs = d_open;  // n*PW words fit (reused later)
+  int trc = kind == KIND_G1   ? g1_generate_trace_device(d_sc, d_x, d_off, n, d_tvals, N, d_scr, d_outs, d_err, st)
+            : kind == KIND_G2 ? g2_generate_trace_device(d_sc, d_x, d_off, n, d_tvals, N, d_scr, d_outs, d_err, st)
+                              : fq_generate_trace_device(d_sc, d_x, n, d_tvals, N, d_scr, d_outs, d_err, st);
+  if (trc) {
     err = "trace generation launch failed";
     return BN254S_E_HIP;
   }
-  pr->outputs.resize(n * 8);
+  pr->outputs.resize(n * (size_t)PW);
   int h_err = 0;
-  CHK(hipMemcpyAsync(pr->outputs.data(), d_outs, n * 64, hipMemcpyDeviceToHost, st));
+  CHK(hipMemcpyAsync(pr->outputs.data(), d_outs, n * (size_t)PW * 8, hipMemcpyDeviceToHost, st));
   CHK(hipMemcpyAsync(&h_err, d_err, 4, hipMemcpyDeviceToHost, st));
   se(ST_TRACE);
 
@@ -285,7 +304,9 @@ static int prove_g1_on_slot(bn254s_ctx* c, Slot& sl, const bn254s_params& P, con
   // ---- quotient ---------------------------------------------------------------------------------------------
   {
     std::vector<u64> hW, hmzt;
-    g1_quotient_host_tables(sh, alphas, hW, hmzt);
+    const int* mz_e0 = nullptr;
+    int nblk = kind == KIND_G1 ? g1_quotient_mz_blocks(&mz_e0) : kind == KIND_G2 ? g2_quotient_mz_blocks(&mz_e0) : fq_quotient_mz_blocks(&mz_e0);
+    quotient_host_tables(K, alphas, mz_e0, nblk, hW, hmzt);
     CHK(hipMemcpyAsync(d_W, hW.data(), hW.size() * 8, hipMemcpyHostToDevice, st));
     CHK(hipMemcpyAsync(d_mzt, hmzt.data(), hmzt.size() * 8, hipMemcpyHostToDevice, st));
     CHK(hipStreamSynchronize(st));  // host vectors go out of scope
@@ -293,7 +314,11 @@ static int prove_g1_on_slot(bn254s_ctx* c, Slot& sl, const bn254s_params& P, con
   {
     BigSection big(c, st);
     sb(ST_QUOTIENT);
-    g1_quotient_launch(sh, d_tlde, d_alde, d_W, d_mzt, pt, betas, gammas, log_n, d_qv, st);
+    QArgs QA;
+    quotient_fill_args(QA, sh, d_tlde, d_alde, d_W, d_mzt, pt, betas, gammas, log_n, d_qv);
+    if (kind == KIND_G1) g1_quotient_launch(QA, sh, st);
+    else if (kind == KIND_G2) g2_quotient_launch(QA, sh, st);
+    else fq_quotient_launch(QA, sh, st);
   }
   for (int a = 0; a < 2; a++)
     for (int h = 0; h < 2; h++)
@@ -522,7 +547,7 @@ int bn254s_prove_g1(bn254s_ctx* c, const bn254s_params* params, const uint64_t* 
   Slot* sl = c->slot(0);
   if (!sl) return BN254S_E_HIP;
   bn254s_proof* pr = new bn254s_proof();
-  int rc = prove_g1_on_slot(c, *sl, *params, scalars, x, off, n, pr, c->err);
+  int rc = prove_on_slot(c, *sl, KIND_G1, *params, scalars, x, off, n, pr, c->err);
   if (rc != BN254S_OK) {
     hipStreamSynchronize(sl->st);
     delete pr;
@@ -557,7 +582,7 @@ int bn254s_prove_g1_batch(bn254s_ctx* c, const bn254s_params* params, const uint
         if (i >= n_proofs || first_rc.load() != 0) break;
         size_t b = i * per_proof, cnt = std::min(per_proof, n_total - b);
         bn254s_proof* pr = new bn254s_proof();
-        int rc = prove_g1_on_slot(c, *c->slots[s], *params, scalars + 4 * b, x + 8 * b, off + 8 * b, cnt, pr, errs[s]);
+        int rc = prove_on_slot(c, *c->slots[s], KIND_G1, *params, scalars + 4 * b, x + 8 * b, off + 8 * b, cnt, pr, errs[s]);
         if (rc != BN254S_OK) {
           hipStreamSynchronize(c->slots[s]->st);
           delete pr;
@@ -581,15 +606,31 @@ int bn254s_prove_g1_batch(bn254s_ctx* c, const bn254s_params* params, const uint
   return BN254S_OK;
 }
 
-int bn254s_prove_g2(bn254s_ctx* c, const bn254s_params*, const uint64_t*, const uint64_t*, const uint64_t*, size_t,
-                    bn254s_proof**) {
-  if (c) c->err = "G2 scalar-mul STARK: not implemented in this build";
-  return BN254S_E_UNSUPPORTED;
+static int prove_one(bn254s_ctx* c, int kind, const bn254s_params* params, const uint64_t* scalars, const uint64_t* x,
+                     const uint64_t* off, size_t n, bn254s_proof** out) {
+  if (!c || !params || !scalars || !x || (kind != KIND_FQ && !off) || !out || n == 0 || params->struct_size != sizeof(bn254s_params))
+    return BN254S_E_INVALID_ARG;
+  *out = nullptr;
+  HIP_TRY(c, hipSetDevice(c->device));
+  Slot* sl = c->slot(0);
+  if (!sl) return BN254S_E_HIP;
+  bn254s_proof* pr = new bn254s_proof();
+  int rc = prove_on_slot(c, *sl, kind, *params, scalars, x, off, n, pr, c->err);
+  if (rc != BN254S_OK) {
+    hipStreamSynchronize(sl->st);
+    delete pr;
+    return rc;
+  }
+  *out = pr;
+  return BN254S_OK;
 }
-int bn254s_prove_fq_exp(bn254s_ctx* c, const bn254s_params*, const uint64_t*, const uint64_t*, const uint64_t*, size_t,
-                        bn254s_proof**) {
-  if (c) c->err = "Fq exponentiation STARK: not implemented in this build";
-  return BN254S_E_UNSUPPORTED;
+int bn254s_prove_g2(bn254s_ctx* c, const bn254s_params* params, const uint64_t* scalars, const uint64_t* x, const uint64_t* off,
+                    size_t n, bn254s_proof** out) {
+  return prove_one(c, KIND_G2, params, scalars, x, off, n, out);
+}
+int bn254s_prove_fq_exp(bn254s_ctx* c, const bn254s_params* params, const uint64_t* scalars, const uint64_t* x, size_t n,
+                        bn254s_proof** out) {
+  return prove_one(c, KIND_FQ, params, scalars, x, nullptr, n, out);
 }
 
 int bn254s_proof_words(const bn254s_proof* p, const uint64_t** data, size_t* len) {
@@ -620,39 +661,51 @@ size_t bn254s_proof_serialize(const bn254s_proof* p, uint8_t* buf, size_t cap) {
 }
 void bn254s_proof_free(bn254s_proof* p) { delete p; }
 
-int bn254s_g1_generate_trace(bn254s_ctx* c, const uint64_t* scalars, const uint64_t* x, const uint64_t* off, size_t n,
-                             uint32_t min_rows_log2, uint64_t* trace_out, uint64_t* outputs) {
-  if (!c || !scalars || !x || !off || n == 0 || !trace_out) return BN254S_E_INVALID_ARG;
+int bn254s_generate_trace(bn254s_ctx* c, int kind, const uint64_t* scalars, const uint64_t* x, const uint64_t* off, size_t n,
+                          uint32_t min_rows_log2, uint64_t* trace_out, uint64_t* outputs) {
+  if (!c || kind < 0 || kind > 2 || !scalars || !x || (kind != KIND_FQ && !off) || n == 0 || !trace_out) return BN254S_E_INVALID_ARG;
   if (min_rows_log2 < 16) {  // the range-check table needs all 2^16 values (scalar_mul_stark.rs:71-87)
     c->err = "min_rows_log2 must be >= 16";
     return BN254S_E_INVALID_ARG;
   }
   HIP_TRY(c, hipSetDevice(c->device));
+  const int PW = point_words(kind);
+  const StarkShape sh = shape_for(kind);
   size_t N = rows_for(n, min_rows_log2);
-  u64* d_in = c->words("g1.in", n * 20);
-  u64* d_trace = c->words("g1.trace", (size_t)G1_W * N);
-  u64* d_scr = c->words("g1.scratch", g1_trace_scratch_words(n));
-  u64* d_out = c->words("g1.out", n * 8 + 8);
+  const size_t in_words = n * (4 + 2 * (size_t)PW);
+  u64* d_in = c->words("gt.in", in_words);
+  u64* d_trace = c->words("gt.trace", (size_t)sh.W * N);
+  const size_t trace_scr = kind == KIND_G1 ? g1_trace_scratch_words(n) : kind == KIND_G2 ? g2_trace_scratch_words(n) : fq_trace_scratch_words(n);
+  u64* d_scr = c->words("gt.scratch", trace_scr);
+  u64* d_out = c->words("gt.out", n * PW + 8);
   if (!d_in || !d_trace || !d_scr || !d_out) return BN254S_E_OOM;
-  int* d_err = (int*)(d_out + n * 8);
+  int* d_err = (int*)(d_out + n * PW);
+  u64 *d_sc = d_in, *d_x = d_in + 4 * n, *d_off = d_x + (size_t)PW * n;
   HIP_TRY(c, hipMemsetAsync(d_err, 0, 4, c->stream));
-  HIP_TRY(c, hipMemcpyAsync(d_in, scalars, n * 32, hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(c, hipMemcpyAsync(d_in + 4 * n, x, n * 64, hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(c, hipMemcpyAsync(d_in + 12 * n, off, n * 64, hipMemcpyHostToDevice, c->stream));
-  if (g1_generate_trace_device(d_in, d_in + 4 * n, d_in + 12 * n, n, d_trace, N, d_scr, d_out, d_err, c->stream)) {
+  HIP_TRY(c, hipMemcpyAsync(d_sc, scalars, n * 32, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(d_x, x, n * (size_t)PW * 8, hipMemcpyHostToDevice, c->stream));
+  if (kind != KIND_FQ) HIP_TRY(c, hipMemcpyAsync(d_off, off, n * (size_t)PW * 8, hipMemcpyHostToDevice, c->stream));
+  int trc = kind == KIND_G1   ? g1_generate_trace_device(d_sc, d_x, d_off, n, d_trace, N, d_scr, d_out, d_err, c->stream)
+            : kind == KIND_G2 ? g2_generate_trace_device(d_sc, d_x, d_off, n, d_trace, N, d_scr, d_out, d_err, c->stream)
+                              : fq_generate_trace_device(d_sc, d_x, n, d_trace, N, d_scr, d_out, d_err, c->stream);
+  if (trc) {
     c->err = "trace generation launch failed";
     return BN254S_E_HIP;
   }
   int h_err = 0;
   HIP_TRY(c, hipMemcpyAsync(&h_err, d_err, 4, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipMemcpyAsync(trace_out, d_trace, (size_t)G1_W * N * 8, hipMemcpyDeviceToHost, c->stream));
-  if (outputs) HIP_TRY(c, hipMemcpyAsync(outputs, d_out, n * 64, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(trace_out, d_trace, (size_t)sh.W * N * 8, hipMemcpyDeviceToHost, c->stream));
+  if (outputs) HIP_TRY(c, hipMemcpyAsync(outputs, d_out, n * (size_t)PW * 8, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   if (h_err) {
     c->err = "trace generation reported device error " + std::to_string(h_err);
     return h_err;
   }
   return BN254S_OK;
+}
+int bn254s_g1_generate_trace(bn254s_ctx* c, const uint64_t* scalars, const uint64_t* x, const uint64_t* off, size_t n,
+                             uint32_t min_rows_log2, uint64_t* trace_out, uint64_t* outputs) {
+  return bn254s_generate_trace(c, KIND_G1, scalars, x, off, n, min_rows_log2, trace_out, outputs);
 }
 
 }  // extern "C"

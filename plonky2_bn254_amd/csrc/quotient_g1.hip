@@ -11,7 +11,7 @@
 // witness, so their alpha-weighted sum is re-associated:
 //   sum_i w_i*constr_i = qsign * sum_j quot_j * M_j  +  sum_d (lo_d*u_d + hi_d*B*u_d) - off*sum u_d  -  sum_i w_i*input_i
 // with M_j = sum_t w_{j+t} m_t and u_d = w_{d+1} - B*w_d depending on alpha only (host-precomputed).
-#include "quotient_common.h"
+#include "quotient_sched.h"
 #include "trace_g1.h"
 #include "quotient.h"
 
@@ -19,90 +19,7 @@ static constexpr int G1_K_AIR = 1111;
 // first constraint index of the five eval_modulus_zero blocks inside eval_g1_add
 static constexpr int G1_MZ_E0[5] = {0, 50, 83, 132, 165};
 
-struct G1QArgs {
-  const u64* tl;   // trace LDE [781][2N], bit-reversed order
-  const u64* al;   // aux LDE [456][2N]
-  const u64* W;    // weights [2][K]
-  const u64* mzt;  // modulus-zero tables [5][2][80]
-  QPointTables pt;
-  u64 betas[2], gammas[2];
-  u64 zh_inv[2];   // 1/Z_H on coset h
-  u64 w_inv;       // w_N^-1 (last element of the subgroup)
-  u64* out;        // [2 alphas][2 cosets][N] natural order
-  unsigned log_n;
-  int K;
-};
-
-#define TL(c) tl[(size_t)(c)*M2 + j]
-#define TN(c) tl[(size_t)(c)*M2 + jn]
-
-__device__ __forceinline__ void ld16(const u64* __restrict__ tl, size_t M2, size_t j, int col, u64* v) {
-#pragma unroll
-  for (int i = 0; i < 16; i++) v[i] = tl[(size_t)(col + i) * M2 + j];
-}
-// coefficient i of the limb product A*B (pol_mul_wide), reduced
-__device__ __forceinline__ u64 conv16(const u64* A, const u64* B, int i) {
-  Acc a;
-  acc_init(a);
-#pragma unroll
-  for (int s = 0; s < 16; s++) {
-    int t = i - s;
-    if (t >= 0 && t < 16) acc_mad(a, A[s], B[t]);
-  }
-  return acc_red(a);
-}
-
-// One eval_modulus_zero block.  `in(i)` returns coefficient i (0..30) of the input polynomial.
-template <class InFn>
-__device__ __forceinline__ void mz_block(const u64* __restrict__ tl, size_t M2, size_t j, int auxcol, const u64* __restrict__ w0,
-                                         const u64* __restrict__ w1, const u64* __restrict__ T0, const u64* __restrict__ T1,
-                                         u64 filter, InFn in, u64& tot0, u64& tot1) {
-  Acc2 pos, neg, q;
-  acc2_init(pos);
-  acc2_init(neg);
-  acc2_init(q);
-  const u64 iqp = TL(auxcol + MZ_IQP);
-  acc2_mad(pos, gl_sub(gl_mul(iqp, iqp), iqp), w0[0], w1[0]);
-  const u64 qsign = gl_sub(gl_dbl(iqp), 1);
-#pragma unroll
-  for (int jj = 0; jj < 17; jj++) acc2_mad(q, TL(auxcol + MZ_QUOT + jj), T0[jj], T1[jj]);
-#pragma unroll
-  for (int d = 0; d < 31; d++) {
-    acc2_mad(pos, TL(auxcol + MZ_LO + d), T0[17 + d], T1[17 + d]);
-    acc2_mad(pos, TL(auxcol + MZ_HI + d), T0[48 + d], T1[48 + d]);
-  }
-#pragma unroll
-  for (int i = 0; i < 31; i++) acc2_mad(neg, in(i), w0[1 + i], w1[1 + i]);
-  u64 s0 = gl_add(acc_red(pos.a0), gl_mul(qsign, acc_red(q.a0)));
-  u64 s1 = gl_add(acc_red(pos.a1), gl_mul(qsign, acc_red(q.a1)));
-  s0 = gl_sub(gl_sub(s0, T0[79]), acc_red(neg.a0));
-  s1 = gl_sub(gl_sub(s1, T1[79]), acc_red(neg.a1));
-  tot0 = gl_add(tot0, gl_mul(filter, s0));
-  tot1 = gl_add(tot1, gl_mul(filter, s1));
-}
-
-// sum_i (a[i] - b[i]) * w[e+i] for both alphas, times `filter`
-#define EQ_GROUP(filter, n, AEXPR, BEXPR)                         \
-  {                                                               \
-    Acc2 g_;                                                      \
-    acc2_init(g_);                                                \
-    for (int i = 0; i < (n); i++) {                               \
-      acc2_mad(g_, gl_sub((AEXPR), (BEXPR)), W0[e + i], W1[e + i]); \
-    }                                                             \
-    e += (n);                                                     \
-    u64 f_ = (filter);                                            \
-    tot0 = gl_add(tot0, gl_mul(f_, acc_red(g_.a0)));              \
-    tot1 = gl_add(tot1, gl_mul(f_, acc_red(g_.a1)));              \
-  }
-#define EMIT(c)                                  \
-  {                                              \
-    u64 c_ = (c);                                \
-    tot0 = gl_add(tot0, gl_mul(c_, W0[e]));      \
-    tot1 = gl_add(tot1, gl_mul(c_, W1[e]));      \
-    e += 1;                                      \
-  }
-
-__global__ __launch_bounds__(256) void k_quotient_g1(G1QArgs A, StarkShape sh) {
+__global__ __launch_bounds__(256) void k_quotient_g1(QArgs A, StarkShape sh) {
   const unsigned log_n = A.log_n;
   const size_t N = (size_t)1 << log_n, M2 = 2 * N;
   const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -202,68 +119,7 @@ __global__ __launch_bounds__(256) void k_quotient_g1(G1QArgs A, StarkShape sh) {
     e = 198;
   }
 
-  // ---- eval_packed_generic body (scalar_mul_stark.rs:257-339) ------------------------------------------
-  const u64 is_first = TL(G1_COL_FLAGS + 0), is_last = TL(G1_COL_FLAGS + 1);
-  const u64 n_filter = TN(G1_COL_FILTER), n_is_last = TN(G1_COL_FLAGS + 1);
-  const u64 is_not_last_round = gl_sub(filter, is_last);
-  const u64 is_next_not_last_round = gl_sub(n_filter, n_is_last);
-  const u64 is_adding = TL(G1_COL_IS_ADDING), idnl = TL(G1_COL_IDNL);
-  const u64 n_is_adding = TN(G1_COL_IS_ADDING), n_idnl = TN(G1_COL_IDNL);
-  const u64 bit0 = TL(G1_COL_BITS), n_bit0 = TN(G1_COL_BITS);
-
-  EMIT(gl_mul(is_first, gl_sub(is_adding, 1)));                                          // 198
-  EQ_GROUP(is_first, 32, TL(G1_COL_DOUBLE + i), TL(G1_COL_B + i));                       // 199
-  EQ_GROUP(gl_mul(bit0, is_first), 32, TL(G1_COL_SUM + i), TL(G1_COL_C + i));            // 231
-  EQ_GROUP(gl_mul(gl_sub(1, bit0), is_first), 32, TL(G1_COL_SUM + i), TL(G1_COL_A + i)); // 263
-  // doubling step -> addition step
-  EQ_GROUP(idnl, 32, TN(G1_COL_A + i), TL(G1_COL_SUM + i));                              // 295
-  EQ_GROUP(idnl, 32, TN(G1_COL_B + i), TL(G1_COL_DOUBLE + i));                           // 327
-  EQ_GROUP(gl_mul(n_bit0, idnl), 32, TN(G1_COL_SUM + i), TN(G1_COL_C + i));              // 359
-  EQ_GROUP(gl_mul(gl_sub(1, n_bit0), idnl), 32, TN(G1_COL_SUM + i), TN(G1_COL_A + i));   // 391
-  EQ_GROUP(idnl, 32, TN(G1_COL_DOUBLE + i), TL(G1_COL_DOUBLE + i));                      // 423
-  EMIT(gl_mul(idnl, gl_sub(n_is_adding, 1)));                                            // 455
-  EMIT(gl_mul(idnl, n_idnl));                                                            // 456
-  EQ_GROUP(idnl, 256, TN(G1_COL_BITS + i), TL(G1_COL_BITS + ((i + 1) & 255)));           // 457
-  // addition step -> doubling step
-  EQ_GROUP(is_adding, 32, TN(G1_COL_A + i), TL(G1_COL_DOUBLE + i));                      // 713
-  EQ_GROUP(is_adding, 32, TN(G1_COL_B + i), TL(G1_COL_DOUBLE + i));                      // 745
-  EQ_GROUP(is_adding, 32, TN(G1_COL_SUM + i), TL(G1_COL_SUM + i));                       // 777
-  EQ_GROUP(is_adding, 32, TN(G1_COL_DOUBLE + i), TN(G1_COL_C + i));                      // 809
-  EMIT(gl_mul(is_adding, n_is_adding));                                                  // 841
-  EMIT(gl_mul(is_adding, gl_sub(n_idnl, is_next_not_last_round)));                       // 842
-  EQ_GROUP(is_adding, 256, TN(G1_COL_BITS + i), TL(G1_COL_BITS + i));                    // 843
-  // eval_round_flags (round_flags.rs:46-81), period 512
-  {
-    const u64 counter = TL(G1_COL_FLAGS + 2), inv_c = TL(G1_COL_FLAGS + 3), inv_cp = TL(G1_COL_FLAGS + 4);
-    const u64 n_counter = TN(G1_COL_FLAGS + 2);
-    const u64 not_filter = gl_sub(1, filter);
-    EMIT(gl_mul(not_filter, is_first));
-    EMIT(gl_mul(not_filter, is_last));
-    EMIT(gl_mul(filter, gl_sub(gl_mul(counter, inv_c), gl_sub(1, is_first))));
-    EMIT(gl_mul(gl_mul(filter, counter), is_first));
-    const u64 cp = gl_sub(counter, 511);
-    EMIT(gl_mul(filter, gl_sub(gl_mul(cp, inv_cp), gl_sub(1, is_last))));
-    EMIT(gl_mul(gl_mul(filter, cp), is_last));
-    EMIT(gl_mul(gl_mul(filter, gl_sub(1, is_last)), gl_sub(gl_sub(n_counter, counter), 1)));
-    EMIT(gl_mul(gl_mul(filter, is_last), n_counter));
-  }
-  EMIT(gl_mul(is_not_last_round, gl_sub(TN(G1_COL_TIMESTAMP), TL(G1_COL_TIMESTAMP))));   // 1107
-  EMIT(gl_mul(is_not_last_round, gl_sub(n_filter, filter)));                             // 1108
-  const u64 x = A.pt.x[j], lfirst = A.pt.lfirst[j], llast = A.pt.llast[j];
-  const u64 z_last = gl_sub(x, A.w_inv);
-  {
-    const u64 rc = TL(G1_COL_RANGE), diff = gl_sub(TN(G1_COL_RANGE), rc);
-    EMIT(gl_mul(gl_sub(gl_mul(diff, diff), diff), z_last));                              // 1109 transition
-    EMIT(gl_mul(gl_sub(rc, 65535), llast));                                              // 1110 last row
-  }
-  // ---- lookups + CTLs --------------------------------------------------------------------------------------
-  lookup_and_ctl_constraints(sh, tl, A.al, M2, j, jn, W0, W1, e, A.betas, A.gammas, lfirst, llast, z_last, tot0, tot1);
-
-  // divide by Z_H and store in natural order of the coset
-  const size_t h = j >> log_n;
-  const u32 k = bitrev32((u32)(j & (N - 1)), log_n);
-  A.out[(0 * 2 + h) * N + k] = gl_mul(tot0, A.zh_inv[h]);
-  A.out[(1 * 2 + h) * N + k] = gl_mul(tot1, A.zh_inv[h]);
+  schedule_and_finish<G1L, false>(A, sh, j, jn, e, tot0, tot1);
 }
 
 // ---- per-context point tables ---------------------------------------------------------------------------------
@@ -291,9 +147,7 @@ void quotient_point_tables(u64* d_x, u64* d_lfirst, u64* d_llast, unsigned log_n
 }
 
 // ---- host: alpha-dependent tables ---------------------------------------------------------------------------
-// W[a][e] = alpha_a^(K-1-e); mzt[blk][a][80] = {M_j (17), u_d (31), B*u_d (31), off*sum(u_d)}
-void g1_quotient_host_tables(const StarkShape& sh, const u64 alphas[2], std::vector<u64>& W, std::vector<u64>& mzt) {
-  const int K = sh.n_total_constraints();
+void quotient_host_tables(int K, const u64 alphas[2], const int* mz_e0, int n_blocks, std::vector<u64>& W, std::vector<u64>& mzt) {
   W.assign(2 * (size_t)K, 0);
   for (int a = 0; a < 2; a++) {
     u64 v = 1;
@@ -305,10 +159,10 @@ void g1_quotient_host_tables(const StarkShape& sh, const u64 alphas[2], std::vec
   static const u64 MOD[16] = {64839, 55420, 35862, 15392, 51853, 26737, 27281, 38785,
                               22621, 33153, 17846, 47184, 41001, 57649, 20082, 12388};
   const u64 B = 1ULL << 16, OFF = 1ULL << 29;
-  mzt.assign(5 * 2 * 80, 0);
-  for (int blk = 0; blk < 5; blk++)
+  mzt.assign((size_t)n_blocks * 2 * 80, 0);
+  for (int blk = 0; blk < n_blocks; blk++)
     for (int a = 0; a < 2; a++) {
-      const u64* w = &W[(size_t)a * K + G1_MZ_E0[blk] + 1];  // w[i], i = 0..31: weight of constr_i
+      const u64* w = &W[(size_t)a * K + mz_e0[blk] + 1];  // w[i], i = 0..31: weight of constr_i
       u64* T = &mzt[(size_t)(blk * 2 + a) * 80];
       for (int jj = 0; jj < 17; jj++) {
         u64 s = 0;
@@ -327,10 +181,8 @@ void g1_quotient_host_tables(const StarkShape& sh, const u64 alphas[2], std::vec
     }
 }
 
-void g1_quotient_launch(const StarkShape& sh, const u64* d_tl, const u64* d_al, const u64* d_W, const u64* d_mzt,
-                        const QPointTables& pt, const u64 betas[2], const u64 gammas[2], unsigned log_n, u64* d_out,
-                        hipStream_t st) {
-  G1QArgs A;
+void quotient_fill_args(QArgs& A, const StarkShape& sh, const u64* d_tl, const u64* d_al, const u64* d_W, const u64* d_mzt,
+                        const QPointTables& pt, const u64 betas[2], const u64 gammas[2], unsigned log_n, u64* d_out) {
   A.tl = d_tl;
   A.al = d_al;
   A.W = d_W;
@@ -348,6 +200,13 @@ void g1_quotient_launch(const StarkShape& sh, const u64* d_tl, const u64* d_al, 
   A.out = d_out;
   A.log_n = log_n;
   A.K = sh.n_total_constraints();
-  size_t M2 = 2 * N;
+}
+
+int g1_quotient_mz_blocks(const int** e0) {
+  *e0 = G1_MZ_E0;
+  return 5;
+}
+void g1_quotient_launch(const QArgs& A, const StarkShape& sh, hipStream_t st) {
+  size_t M2 = (size_t)2 << A.log_n;
   k_quotient_g1<<<(unsigned)((M2 + 255) / 256), 256, 0, st>>>(A, sh);
 }

@@ -1,0 +1,182 @@
+// Constraint-evaluation pieces shared by the three quotient kernels: kernel arguments, the
+// eval_modulus_zero block with re-associated weights, and the 512-row schedule constraints
+// (everything in eval_packed_generic after the add / mul check: reference
+// src/starks/curves/g1/scalar_mul_stark.rs:257-339 == curves/g2/scalar_mul_stark.rs, src/starks/fields/exp_stark.rs:241-327).
+#pragma once
+#include <vector>
+#include "quotient_common.h"
+#include "layout.h"
+
+// ModulusZeroAux block: [is_quot_positive, quot_abs[17], aux_lo[31], aux_hi[31]] (modulus_zero.rs:66-73)
+#ifndef MZ_CONSTS
+#define MZ_CONSTS
+static constexpr int QMZ_IQP = 0, QMZ_QUOT = 1, QMZ_LO = 18, QMZ_HI = 49;
+#endif
+
+struct QArgs {
+  const u64* tl;   // trace LDE [W][2N], bit-reversed order
+  const u64* al;   // aux LDE [A][2N]
+  const u64* W;    // weights [2][K]
+  const u64* mzt;  // modulus-zero tables [n_blocks][2][80]
+  QPointTables pt;
+  u64 betas[2], gammas[2];
+  u64 zh_inv[2];   // 1/Z_H on coset h
+  u64 w_inv;       // w_N^-1 (last element of the subgroup)
+  u64* out;        // [2 alphas][2 cosets][N] natural order
+  unsigned log_n;
+  int K;
+};
+
+#define TL(c) tl[(size_t)(c)*M2 + j]
+#define TN(c) tl[(size_t)(c)*M2 + jn]
+
+__device__ __forceinline__ void ld16(const u64* __restrict__ tl, size_t M2, size_t j, int col, u64* v) {
+#pragma unroll
+  for (int i = 0; i < 16; i++) v[i] = tl[(size_t)(col + i) * M2 + j];
+}
+// coefficient i of the limb product A*B (pol_mul_wide), reduced
+__device__ __forceinline__ u64 conv16(const u64* A, const u64* B, int i) {
+  Acc a;
+  acc_init(a);
+#pragma unroll
+  for (int s = 0; s < 16; s++) {
+    int t = i - s;
+    if (t >= 0 && t < 16) acc_mad(a, A[s], B[t]);
+  }
+  return acc_red(a);
+}
+
+// One eval_modulus_zero block.  `in(i)` returns coefficient i (0..30) of the input polynomial.
+template <class InFn>
+__device__ __forceinline__ void mz_block(const u64* __restrict__ tl, size_t M2, size_t j, int auxcol, const u64* __restrict__ w0,
+                                         const u64* __restrict__ w1, const u64* __restrict__ T0, const u64* __restrict__ T1,
+                                         u64 filter, InFn in, u64& tot0, u64& tot1) {
+  Acc2 pos, neg, q;
+  acc2_init(pos);
+  acc2_init(neg);
+  acc2_init(q);
+  const u64 iqp = TL(auxcol + QMZ_IQP);
+  acc2_mad(pos, gl_sub(gl_mul(iqp, iqp), iqp), w0[0], w1[0]);
+  const u64 qsign = gl_sub(gl_dbl(iqp), 1);
+#pragma unroll
+  for (int jj = 0; jj < 17; jj++) acc2_mad(q, TL(auxcol + QMZ_QUOT + jj), T0[jj], T1[jj]);
+#pragma unroll
+  for (int d = 0; d < 31; d++) {
+    acc2_mad(pos, TL(auxcol + QMZ_LO + d), T0[17 + d], T1[17 + d]);
+    acc2_mad(pos, TL(auxcol + QMZ_HI + d), T0[48 + d], T1[48 + d]);
+  }
+#pragma unroll
+  for (int i = 0; i < 31; i++) acc2_mad(neg, in(i), w0[1 + i], w1[1 + i]);
+  u64 s0 = gl_add(acc_red(pos.a0), gl_mul(qsign, acc_red(q.a0)));
+  u64 s1 = gl_add(acc_red(pos.a1), gl_mul(qsign, acc_red(q.a1)));
+  s0 = gl_sub(gl_sub(s0, T0[79]), acc_red(neg.a0));
+  s1 = gl_sub(gl_sub(s1, T1[79]), acc_red(neg.a1));
+  tot0 = gl_add(tot0, gl_mul(filter, s0));
+  tot1 = gl_add(tot1, gl_mul(filter, s1));
+}
+
+// sum_i (a[i] - b[i]) * w[e+i] for both alphas, times `filter`
+#define EQ_GROUP(filter, n, AEXPR, BEXPR)                         \
+  {                                                               \
+    Acc2 g_;                                                      \
+    acc2_init(g_);                                                \
+    for (int i = 0; i < (n); i++) {                               \
+      acc2_mad(g_, gl_sub((AEXPR), (BEXPR)), W0[e + i], W1[e + i]); \
+    }                                                             \
+    e += (n);                                                     \
+    u64 f_ = (filter);                                            \
+    tot0 = gl_add(tot0, gl_mul(f_, acc_red(g_.a0)));              \
+    tot1 = gl_add(tot1, gl_mul(f_, acc_red(g_.a1)));              \
+  }
+#define EMIT(c)                                  \
+  {                                              \
+    u64 c_ = (c);                                \
+    tot0 = gl_add(tot0, gl_mul(c_, W0[e]));      \
+    tot1 = gl_add(tot1, gl_mul(c_, W1[e]));      \
+    e += 1;                                      \
+  }
+
+
+// Schedule constraints starting at constraint index e (e is advanced), then lookups + CTLs, then the division by
+// Z_H and the store.  L = LayoutT<..>.
+template <class L, bool FIRST_A_IS_ONE>
+__device__ __forceinline__ void schedule_and_finish(const QArgs& A, const StarkShape& sh, size_t j, size_t jn, int e, u64 tot0,
+                                                    u64 tot1) {
+  const unsigned log_n = A.log_n;
+  const size_t N = (size_t)1 << log_n, M2 = 2 * N;
+  const u64* __restrict__ tl = A.tl;
+  const u64* __restrict__ W0 = A.W;
+  const u64* __restrict__ W1 = A.W + A.K;
+  const u64 filter = TL(L::FILTER);
+  // ---- eval_packed_generic body (scalar_mul_stark.rs:257-339) ------------------------------------------
+  const u64 is_first = TL(L::FLAGS + 0), is_last = TL(L::FLAGS + 1);
+  const u64 n_filter = TN(L::FILTER), n_is_last = TN(L::FLAGS + 1);
+  const u64 is_not_last_round = gl_sub(filter, is_last);
+  const u64 is_next_not_last_round = gl_sub(n_filter, n_is_last);
+  const u64 is_adding = TL(L::IS_ADDING), idnl = TL(L::IDNL);
+  const u64 n_is_adding = TN(L::IS_ADDING), n_idnl = TN(L::IDNL);
+  const u64 bit0 = TL(L::BITS), n_bit0 = TN(L::BITS);
+
+  EMIT(gl_mul(is_first, gl_sub(is_adding, 1)));                                          // 198
+  EQ_GROUP(is_first, L::PL, TL(L::DOUBLE + i), TL(L::B + i));                       // 199
+  EQ_GROUP(gl_mul(bit0, is_first), L::PL, TL(L::SUM + i), TL(L::C + i));            // 231
+  EQ_GROUP(gl_mul(gl_sub(1, bit0), is_first), L::PL, TL(L::SUM + i), TL(L::A + i)); // 263
+  if (FIRST_A_IS_ONE) {  // Fq exp: first round, a = 1 (exp_stark.rs:250-256)
+    EQ_GROUP(is_first, L::PL, TL(L::A + i), (u64)(i == 0 ? 1 : 0));
+  }
+  // doubling step -> addition step
+  EQ_GROUP(idnl, L::PL, TN(L::A + i), TL(L::SUM + i));                              // 295
+  EQ_GROUP(idnl, L::PL, TN(L::B + i), TL(L::DOUBLE + i));                           // 327
+  EQ_GROUP(gl_mul(n_bit0, idnl), L::PL, TN(L::SUM + i), TN(L::C + i));              // 359
+  EQ_GROUP(gl_mul(gl_sub(1, n_bit0), idnl), L::PL, TN(L::SUM + i), TN(L::A + i));   // 391
+  EQ_GROUP(idnl, L::PL, TN(L::DOUBLE + i), TL(L::DOUBLE + i));                      // 423
+  EMIT(gl_mul(idnl, gl_sub(n_is_adding, 1)));                                            // 455
+  EMIT(gl_mul(idnl, n_idnl));                                                            // 456
+  EQ_GROUP(idnl, 256, TN(L::BITS + i), TL(L::BITS + ((i + 1) & 255)));           // 457
+  // addition step -> doubling step
+  EQ_GROUP(is_adding, L::PL, TN(L::A + i), TL(L::DOUBLE + i));                      // 713
+  EQ_GROUP(is_adding, L::PL, TN(L::B + i), TL(L::DOUBLE + i));                      // 745
+  EQ_GROUP(is_adding, L::PL, TN(L::SUM + i), TL(L::SUM + i));                       // 777
+  EQ_GROUP(is_adding, L::PL, TN(L::DOUBLE + i), TN(L::C + i));                      // 809
+  EMIT(gl_mul(is_adding, n_is_adding));                                                  // 841
+  EMIT(gl_mul(is_adding, gl_sub(n_idnl, is_next_not_last_round)));                       // 842
+  EQ_GROUP(is_adding, 256, TN(L::BITS + i), TL(L::BITS + i));                    // 843
+  // eval_round_flags (round_flags.rs:46-81), period 512
+  {
+    const u64 counter = TL(L::FLAGS + 2), inv_c = TL(L::FLAGS + 3), inv_cp = TL(L::FLAGS + 4);
+    const u64 n_counter = TN(L::FLAGS + 2);
+    const u64 not_filter = gl_sub(1, filter);
+    EMIT(gl_mul(not_filter, is_first));
+    EMIT(gl_mul(not_filter, is_last));
+    EMIT(gl_mul(filter, gl_sub(gl_mul(counter, inv_c), gl_sub(1, is_first))));
+    EMIT(gl_mul(gl_mul(filter, counter), is_first));
+    const u64 cp = gl_sub(counter, 511);
+    EMIT(gl_mul(filter, gl_sub(gl_mul(cp, inv_cp), gl_sub(1, is_last))));
+    EMIT(gl_mul(gl_mul(filter, cp), is_last));
+    EMIT(gl_mul(gl_mul(filter, gl_sub(1, is_last)), gl_sub(gl_sub(n_counter, counter), 1)));
+    EMIT(gl_mul(gl_mul(filter, is_last), n_counter));
+  }
+  EMIT(gl_mul(is_not_last_round, gl_sub(TN(L::TIMESTAMP), TL(L::TIMESTAMP))));   // 1107
+  EMIT(gl_mul(is_not_last_round, gl_sub(n_filter, filter)));                             // 1108
+  const u64 x = A.pt.x[j], lfirst = A.pt.lfirst[j], llast = A.pt.llast[j];
+  const u64 z_last = gl_sub(x, A.w_inv);
+  {
+    const u64 rc = TL(L::RANGE), diff = gl_sub(TN(L::RANGE), rc);
+    EMIT(gl_mul(gl_sub(gl_mul(diff, diff), diff), z_last));                              // 1109 transition
+    EMIT(gl_mul(gl_sub(rc, 65535), llast));                                              // 1110 last row
+  }
+  // ---- lookups + CTLs --------------------------------------------------------------------------------------
+  lookup_and_ctl_constraints(sh, tl, A.al, M2, j, jn, W0, W1, e, A.betas, A.gammas, lfirst, llast, z_last, tot0, tot1);
+
+  // divide by Z_H and store in natural order of the coset
+  const size_t h = j >> log_n;
+  const u32 k = bitrev32((u32)(j & (N - 1)), log_n);
+  A.out[(0 * 2 + h) * N + k] = gl_mul(tot0, A.zh_inv[h]);
+  A.out[(1 * 2 + h) * N + k] = gl_mul(tot1, A.zh_inv[h]);
+}
+
+// W[a][e] = alpha_a^(K-1-e); mzt[blk][a][80] = {M_j (17), u_d (31), B*u_d (31), off*sum(u_d)} for the
+// eval_modulus_zero blocks whose first constraint indices are mz_e0[0..n_blocks).
+void quotient_host_tables(int K, const u64 alphas[2], const int* mz_e0, int n_blocks, std::vector<u64>& W, std::vector<u64>& mzt);
+void quotient_fill_args(QArgs& A, const StarkShape& sh, const u64* d_tl, const u64* d_al, const u64* d_W, const u64* d_mzt,
+                        const QPointTables& pt, const u64 betas[2], const u64 gammas[2], unsigned log_n, u64* d_out);

@@ -1,0 +1,137 @@
+// Shared device helpers of the three trace generators (G1 / G2 / Fq exp): SoA Fq vectors, batched inversion,
+// limb conversion, generate_modulus_zero (reference src/starks/modular/modulus_zero.rs:77-123), round-flag
+// table, and the range-check columns (generate_range_checks).
+#pragma once
+#include "fq_dev.h"
+#include "../../include/bn254_stark.h"
+
+static constexpr int NPTS = 514;  // per instance: 0 = offset | one, 1+k = C_k (k<256), 257+k = D_k (k<=256)
+
+// ---- SoA vectors of Fq elements: element e, limb l at base[l*count + e] ---------------------------------
+__device__ __forceinline__ fq ld_fq(const u64* base, size_t count, size_t e) {
+  fq r;
+#pragma unroll
+  for (int l = 0; l < 4; l++) r.l[l] = base[l * count + e];
+  return r;
+}
+__device__ __forceinline__ void st_fq(u64* base, size_t count, size_t e, const fq& v) {
+#pragma unroll
+  for (int l = 0; l < 4; l++) base[l * count + e] = v.l[l];
+}
+
+// index of the highest set bit of s below position k, or -1
+__device__ __forceinline__ int last_set_below(const u64 s[4], int k) {
+  for (int w = 3; w >= 0; w--) {
+    int lo = w * 64;
+    if (k <= lo) continue;
+    u64 m = s[w];
+    if (k < lo + 64) m &= (1ULL << (k - lo)) - 1;
+    if (m) return lo + 63 - __clzll((long long)m);
+  }
+  return -1;
+}
+// point index of the running sum after step k-1 (S_{k-1}); k = 0 -> offset
+__device__ __forceinline__ int sum_point(const u64 s[4], int k) {
+  int j = last_set_below(s, k);
+  return j < 0 ? 0 : 1 + j;
+}
+
+__device__ __forceinline__ void fq_to_limbs(const fq& mont, int limbs[16]) {
+  fq c = fq_to_canonical(mont);
+#pragma unroll
+  for (int i = 0; i < 16; i++) limbs[i] = (int)((c.l[i >> 2] >> (16 * (i & 3))) & 0xFFFF);
+}
+
+__device__ static constexpr int MOD_LIMBS[16] = {64839, 55420, 35862, 15392, 51853, 26737, 27281, 38785,
+                                                  22621, 33153, 17846, 47184, 41001, 57649, 20082, 12388};
+// p^-1 mod 2^288, 32-bit words
+__device__ static constexpr u32 PINV288[9] = {0x1b799c77u, 0x782df87du, 0xe1359536u, 0x6121829au, 0xe7cc257fu,
+                                               0x2750342fu, 0x6e777394u, 0x0a85dd48u, 0x5b52d390u};
+
+// generate_modulus_zero (modulus_zero.rs:77-123): in = 31 signed limb coefficients of a multiple of p.
+// Writes the 80 witness values to columns col0.. of `row` (trace column-major, N rows).
+static __device__ __noinline__ void gen_modulus_zero(const long long* in, u64* __restrict__ trace, size_t N, size_t row, int col0,
+                                              int* err) {
+  // low 288 bits of V = sum in[i] 2^(16 i), two's complement
+  u32 v[9];
+  long long carry = 0;
+#pragma unroll
+  for (int w = 0; w < 9; w++) {
+    long long t = carry + in[2 * w] + (in[2 * w + 1] << 16);
+    v[w] = (u32)t;
+    carry = t >> 32;
+  }
+  // q = V * p^-1 mod 2^288 (exact quotient, two's complement)
+  u32 q[9];
+  u128 acc = 0;
+#pragma unroll
+  for (int k = 0; k < 9; k++) {
+#pragma unroll
+    for (int i = 0; i <= k; i++) acc += (u64)v[i] * PINV288[k - i];
+    q[k] = (u32)acc;
+    acc >>= 32;
+  }
+  bool neg = (q[8] >> 31) != 0;
+  bool nonzero = false;
+  if (neg) {  // |q| = -q
+    u64 c = 1;
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+      c += (u64)(~q[k]);
+      q[k] = (u32)c;
+      c >>= 32;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 9; k++) nonzero |= q[k] != 0;
+  int qabs[17];
+#pragma unroll
+  for (int i = 0; i < 17; i++) qabs[i] = (int)((q[i >> 1] >> (16 * (i & 1))) & 0xFFFF);
+  if ((q[8] >> 16) != 0) atomicCAS(err, 0, BN254S_E_INTERNAL);  // quotient wider than 17 limbs
+  // constr = in - quot(x) * m(x)
+  long long constr[32];
+#pragma unroll
+  for (int i = 0; i < 31; i++) constr[i] = in[i];
+  constr[31] = 0;
+  const int sgn = neg ? -1 : 1;
+#pragma unroll
+  for (int i = 0; i < 17; i++) {
+    long long qi = (long long)(sgn * qabs[i]);
+#pragma unroll
+    for (int j = 0; j < 16; j++) constr[i + j] -= qi * MOD_LIMBS[j];
+  }
+  u64* out = trace + (size_t)col0 * N + row;
+  out[0] = (!neg && nonzero) ? 1 : 0;
+#pragma unroll
+  for (int i = 0; i < 17; i++) out[(size_t)(1 + i) * N] = (u64)qabs[i];
+  // aux = constr / (x - 2^16) (pol_remove_root_2exp), shifted by 2^29, split in 16-bit halves
+  long long a = -(constr[0] >> 16);
+  bool bad = false;
+#pragma unroll
+  for (int d = 0; d < 31; d++) {
+    if (d > 0) a = (a - constr[d]) >> 16;
+    long long sh = a + (1LL << 29);
+    bad |= (sh < 0) | (sh > (1LL << 30));
+    out[(size_t)(18 + d) * N] = (u64)(sh & 0xFFFF);
+    out[(size_t)(49 + d) * N] = (u64)((sh >> 16) & 0xFFFF);
+  }
+  // exactness: the last carry must vanish, otherwise `in` was not a multiple of p
+  if (bad || a != constr[31]) atomicCAS(err, 0, BN254S_E_INTERNAL);
+}
+
+__device__ __forceinline__ void pol_mul16(const int* a, const int* b, long long* out /*31*/) {
+#pragma unroll
+  for (int i = 0; i < 31; i++) out[i] = 0;
+#pragma unroll
+  for (int i = 0; i < 16; i++)
+#pragma unroll
+    for (int j = 0; j < 16; j++) out[i + j] += (long long)a[i] * b[j];
+}
+
+
+// shared kernels live in trace_g1.hip
+void launch_fq_batch_inv(const u64* in, u64* out, size_t count, hipStream_t st);
+void launch_round_flag_table(u64* tbl, hipStream_t st);
+// histogram of columns [rc_begin, rc_end) -> frequency column, and the range counter column
+void launch_range_columns(u64* trace, size_t N, int rc_begin, int rc_end, int freq_col, int range_col, u32* hist, int* err,
+                          hipStream_t st);

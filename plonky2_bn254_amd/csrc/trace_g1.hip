@@ -14,23 +14,110 @@
 // with Montgomery's batch trick.  Phase B (one thread per trace row): affine a, b, c, lambda and the limb /
 // quotient / carry witnesses; the exact division by p is a multiplication by p^-1 mod 2^288.
 // The trace is written column-major (trace[c*N + row]), so consecutive lanes write consecutive words.
-#include "fq_dev.h"
+#include "trace_common.h"
 #include "trace_g1.h"
 
-// ---- SoA vectors of Fq elements: element e, limb l at base[l*count + e] ---------------------------------
-__device__ __forceinline__ fq ld_fq(const u64* base, size_t count, size_t e) {
-  fq r;
+// ---- batched field inversion ------------------------------------------------------------------------------
+// out[e] = in[e]^-1 (0 -> 0); each thread owns CH elements strided by the grid size.
+template <int CH>
+__global__ __launch_bounds__(64) void k_fq_batch_inv(const u64* __restrict__ in, u64* __restrict__ out, size_t count) {
+  size_t T = (size_t)gridDim.x * blockDim.x, tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  fq v[CH], pre[CH];
+  fq acc = fq_one();
 #pragma unroll
-  for (int l = 0; l < 4; l++) r.l[l] = base[l * count + e];
-  return r;
-}
-__device__ __forceinline__ void st_fq(u64* base, size_t count, size_t e, const fq& v) {
+  for (int j = 0; j < CH; j++) {
+    size_t e = tid + j * T;
+    v[j] = e < count ? ld_fq(in, count, e) : fq_zero();
+    pre[j] = acc;
+    if (!fq_is_zero(v[j])) acc = fq_mul(acc, v[j]);
+  }
+  fq inv = fq_inv(acc);
 #pragma unroll
-  for (int l = 0; l < 4; l++) base[l * count + e] = v.l[l];
+  for (int j = CH - 1; j >= 0; j--) {
+    size_t e = tid + j * T;
+    if (e < count) {
+      if (fq_is_zero(v[j])) {
+        st_fq(out, count, e, fq_zero());
+      } else {
+        st_fq(out, count, e, fq_mul(inv, pre[j]));
+        inv = fq_mul(inv, v[j]);
+      }
+    }
+  }
 }
 
-// Point table per instance: 0 = offset, 1+k = C_k (k<256), 257+k = D_k (k<=256)
-static constexpr int NPTS = 514;
+// Goldilocks inverses of counter and counter-511 for counter in [0,512): computed once per context.
+__global__ void k_round_flag_table(u64* tbl /* [2][512] */) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= 512) return;
+  tbl[c] = c == 0 ? 0 : gl_inv((u64)c);
+  u64 cp = gl_sub((u64)c, 511);
+  tbl[512 + c] = cp == 0 ? 0 : gl_inv(cp);
+}
+
+// ---- range-check columns (generate_range_checks, scalar_mul_stark.rs:71-87) ----------------------------
+// LDS-privatised histogram.  blockIdx.y selects the half of the 2^16 bins kept in LDS (32768 u32 = 128 KB);
+// every block sweeps its slice of the range-checked columns once per half.  The witness columns are far from
+// uniform (aux_hi limbs sit at 2^13 +- 1, many flags are 0/1), so before touching LDS each wave peels off up to
+// two "leader" values with ballots and adds their multiplicity with one atomic.
+__global__ __launch_bounds__(1024) void k_histogram(const u64* __restrict__ trace, size_t N, int col_begin, int col_end,
+                                                    u32* __restrict__ hist, int* __restrict__ err) {
+  __shared__ u32 h[32768];
+  const u32 half = blockIdx.y;
+  for (int b = threadIdx.x; b < 32768; b += blockDim.x) h[b] = 0;
+  __syncthreads();
+  const size_t total = (size_t)(col_end - col_begin) * N;
+  const size_t per = (total + gridDim.x - 1) / gridDim.x;
+  const size_t lo = (size_t)blockIdx.x * per, hi = min(total, lo + per);
+  const u64* src = trace + (size_t)col_begin * N;
+  const int lane = threadIdx.x & 63;
+  for (size_t base = lo; base < hi; base += blockDim.x) {
+    size_t i = base + threadIdx.x;
+    u64 v = i < hi ? src[i] : ~0ULL;
+    if (i < hi && v >= 65536) atomicCAS(err, 0, BN254S_E_INTERNAL);
+    bool active = i < hi && (v >> 15) == half;
+    u32 bin = (u32)v & 32767;
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+      unsigned long long m = __ballot(active);
+      if (m == 0) break;
+      int leader = __ffsll((long long)m) - 1;
+      u32 lv = __shfl(bin, leader);
+      bool same = active && bin == lv;
+      unsigned long long ms = __ballot(same);
+      if (lane == leader) atomicAdd(&h[lv], (u32)__popcll(ms));
+      active = active && !same;
+    }
+    if (active) atomicAdd(&h[bin], 1u);
+  }
+  __syncthreads();
+  for (int b = threadIdx.x; b < 32768; b += blockDim.x) {
+    u32 cnt = h[b];
+    if (cnt) atomicAdd(&hist[half * 32768 + b], cnt);
+  }
+}
+__global__ __launch_bounds__(256) void k_range_columns(u64* __restrict__ trace, size_t N, int freq_col, int range_col,
+                                                       const u32* __restrict__ hist) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  trace[(size_t)range_col * N + i] = i < 65536 ? i : 65535;
+  trace[(size_t)freq_col * N + i] = i < 65536 ? (u64)hist[i] : 0;
+}
+
+
+void launch_fq_batch_inv(const u64* in, u64* out, size_t count, hipStream_t st) {
+  const int CH = 8;
+  size_t threads = (count + CH - 1) / CH;
+  k_fq_batch_inv<CH><<<(unsigned)((threads + 63) / 64), 64, 0, st>>>(in, out, count);
+}
+void launch_round_flag_table(u64* tbl, hipStream_t st) { k_round_flag_table<<<2, 256, 0, st>>>(tbl); }
+void launch_range_columns(u64* trace, size_t N, int rc_begin, int rc_end, int freq_col, int range_col, u32* hist, int* err,
+                          hipStream_t st) {
+  hipMemsetAsync(hist, 0, 65536 * 4, st);
+  k_histogram<<<dim3(128, 2), 1024, 0, st>>>(trace, N, rc_begin, rc_end, hist, err);
+  k_range_columns<<<(unsigned)((N + 255) / 256), 256, 0, st>>>(trace, N, freq_col, range_col, hist);
+}
+
 
 // ---- phase A: the chain -----------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_g1_chain(const u64* __restrict__ scalars, const u64* __restrict__ xs,
@@ -67,35 +154,6 @@ __global__ __launch_bounds__(64) void k_g1_chain(const u64* __restrict__ scalars
   store(513, D);
 }
 
-// ---- batched field inversion ------------------------------------------------------------------------------
-// out[e] = in[e]^-1 (0 -> 0); each thread owns CH elements strided by the grid size.
-template <int CH>
-__global__ __launch_bounds__(64) void k_fq_batch_inv(const u64* __restrict__ in, u64* __restrict__ out, size_t count) {
-  size_t T = (size_t)gridDim.x * blockDim.x, tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  fq v[CH], pre[CH];
-  fq acc = fq_one();
-#pragma unroll
-  for (int j = 0; j < CH; j++) {
-    size_t e = tid + j * T;
-    v[j] = e < count ? ld_fq(in, count, e) : fq_zero();
-    pre[j] = acc;
-    if (!fq_is_zero(v[j])) acc = fq_mul(acc, v[j]);
-  }
-  fq inv = fq_inv(acc);
-#pragma unroll
-  for (int j = CH - 1; j >= 0; j--) {
-    size_t e = tid + j * T;
-    if (e < count) {
-      if (fq_is_zero(v[j])) {
-        st_fq(out, count, e, fq_zero());
-      } else {
-        st_fq(out, count, e, fq_mul(inv, pre[j]));
-        inv = fq_mul(inv, v[j]);
-      }
-    }
-  }
-}
-
 // ---- phase B helpers ------------------------------------------------------------------------------------------
 struct AffPt {
   fq x, y;
@@ -108,23 +166,6 @@ __device__ __forceinline__ AffPt affine_pt(const u64* px, const u64* py, const u
   r.y = fq_mul(fq_mul(ld_fq(py, cnt, e), z2), z);
   return r;
 }
-// index of the highest set bit of s below position k, or -1
-__device__ __forceinline__ int last_set_below(const u64 s[4], int k) {
-  for (int w = 3; w >= 0; w--) {
-    int lo = w * 64;
-    if (k <= lo) continue;
-    u64 m = s[w];
-    if (k < lo + 64) m &= (1ULL << (k - lo)) - 1;
-    if (m) return lo + 63 - __clzll((long long)m);
-  }
-  return -1;
-}
-// point index of the running sum after step k-1 (S_{k-1}); k = 0 -> offset
-__device__ __forceinline__ int sum_point(const u64 s[4], int k) {
-  int j = last_set_below(s, k);
-  return j < 0 ? 0 : 1 + j;
-}
-
 // denominators: add row: b.x - a.x (or 2 a.y when the x coincide); doubling row: 2 a.y
 __global__ __launch_bounds__(64) void k_g1_row_den(const u64* __restrict__ scalars, int n, const u64* __restrict__ px,
                                                    const u64* __restrict__ py, const u64* __restrict__ zi,
@@ -147,107 +188,6 @@ __global__ __launch_bounds__(64) void k_g1_row_den(const u64* __restrict__ scala
     d = fq_dbl(a.y);
   }
   st_fq(den, nrows, r, d);
-}
-
-__device__ __forceinline__ void fq_to_limbs(const fq& mont, int limbs[16]) {
-  fq c = fq_to_canonical(mont);
-#pragma unroll
-  for (int i = 0; i < 16; i++) limbs[i] = (int)((c.l[i >> 2] >> (16 * (i & 3))) & 0xFFFF);
-}
-
-__device__ static constexpr int MOD_LIMBS[16] = {64839, 55420, 35862, 15392, 51853, 26737, 27281, 38785,
-                                                  22621, 33153, 17846, 47184, 41001, 57649, 20082, 12388};
-// p^-1 mod 2^288, 32-bit words
-__device__ static constexpr u32 PINV288[9] = {0x1b799c77u, 0x782df87du, 0xe1359536u, 0x6121829au, 0xe7cc257fu,
-                                               0x2750342fu, 0x6e777394u, 0x0a85dd48u, 0x5b52d390u};
-
-// generate_modulus_zero (modulus_zero.rs:77-123): in = 31 signed limb coefficients of a multiple of p.
-// Writes the 80 witness values to columns col0.. of `row` (trace column-major, N rows).
-__device__ __noinline__ void gen_modulus_zero(const long long* in, u64* __restrict__ trace, size_t N, size_t row, int col0,
-                                              int* err) {
-  // low 288 bits of V = sum in[i] 2^(16 i), two's complement
-  u32 v[9];
-  long long carry = 0;
-#pragma unroll
-  for (int w = 0; w < 9; w++) {
-    long long t = carry + in[2 * w] + (in[2 * w + 1] << 16);
-    v[w] = (u32)t;
-    carry = t >> 32;
-  }
-  // q = V * p^-1 mod 2^288 (exact quotient, two's complement)
-  u32 q[9];
-  u128 acc = 0;
-#pragma unroll
-  for (int k = 0; k < 9; k++) {
-#pragma unroll
-    for (int i = 0; i <= k; i++) acc += (u64)v[i] * PINV288[k - i];
-    q[k] = (u32)acc;
-    acc >>= 32;
-  }
-  bool neg = (q[8] >> 31) != 0;
-  bool nonzero = false;
-  if (neg) {  // |q| = -q
-    u64 c = 1;
-#pragma unroll
-    for (int k = 0; k < 9; k++) {
-      c += (u64)(~q[k]);
-      q[k] = (u32)c;
-      c >>= 32;
-    }
-  }
-#pragma unroll
-  for (int k = 0; k < 9; k++) nonzero |= q[k] != 0;
-  int qabs[17];
-#pragma unroll
-  for (int i = 0; i < 17; i++) qabs[i] = (int)((q[i >> 1] >> (16 * (i & 1))) & 0xFFFF);
-  if ((q[8] >> 16) != 0) atomicCAS(err, 0, BN254S_E_INTERNAL);  // quotient wider than 17 limbs
-  // constr = in - quot(x) * m(x)
-  long long constr[32];
-#pragma unroll
-  for (int i = 0; i < 31; i++) constr[i] = in[i];
-  constr[31] = 0;
-  const int sgn = neg ? -1 : 1;
-#pragma unroll
-  for (int i = 0; i < 17; i++) {
-    long long qi = (long long)(sgn * qabs[i]);
-#pragma unroll
-    for (int j = 0; j < 16; j++) constr[i + j] -= qi * MOD_LIMBS[j];
-  }
-  u64* out = trace + (size_t)col0 * N + row;
-  out[0] = (!neg && nonzero) ? 1 : 0;
-#pragma unroll
-  for (int i = 0; i < 17; i++) out[(size_t)(1 + i) * N] = (u64)qabs[i];
-  // aux = constr / (x - 2^16) (pol_remove_root_2exp), shifted by 2^29, split in 16-bit halves
-  long long a = -(constr[0] >> 16);
-  bool bad = false;
-#pragma unroll
-  for (int d = 0; d < 31; d++) {
-    if (d > 0) a = (a - constr[d]) >> 16;
-    long long sh = a + (1LL << 29);
-    bad |= (sh < 0) | (sh > (1LL << 30));
-    out[(size_t)(18 + d) * N] = (u64)(sh & 0xFFFF);
-    out[(size_t)(49 + d) * N] = (u64)((sh >> 16) & 0xFFFF);
-  }
-  // exactness: the last carry must vanish, otherwise `in` was not a multiple of p
-  if (bad || a != constr[31]) atomicCAS(err, 0, BN254S_E_INTERNAL);
-}
-
-__device__ __forceinline__ void pol_mul16(const int* a, const int* b, long long* out /*31*/) {
-#pragma unroll
-  for (int i = 0; i < 31; i++) out[i] = 0;
-#pragma unroll
-  for (int i = 0; i < 16; i++)
-#pragma unroll
-    for (int j = 0; j < 16; j++) out[i + j] += (long long)a[i] * b[j];
-}
-
-// Goldilocks inverses of counter and counter-511 for counter in [0,512): computed once per context.
-__global__ void k_round_flag_table(u64* tbl /* [2][512] */) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= 512) return;
-  tbl[c] = c == 0 ? 0 : gl_inv((u64)c);
-  u64 cp = gl_sub((u64)c, 511);
-  tbl[512 + c] = cp == 0 ? 0 : gl_inv(cp);
 }
 
 // ---- phase B: one thread per trace row ----------------------------------------------------------------------
@@ -378,55 +318,6 @@ __global__ __launch_bounds__(64) void k_g1_rows(const u64* __restrict__ scalars,
   put(G1_COL_FILTER, 1);
 }
 
-// ---- range-check columns (generate_range_checks, scalar_mul_stark.rs:71-87) ----------------------------
-// LDS-privatised histogram.  blockIdx.y selects the half of the 2^16 bins kept in LDS (32768 u32 = 128 KB);
-// every block sweeps its slice of the range-checked columns once per half.  The witness columns are far from
-// uniform (aux_hi limbs sit at 2^13 +- 1, many flags are 0/1), so before touching LDS each wave peels off up to
-// two "leader" values with ballots and adds their multiplicity with one atomic.
-__global__ __launch_bounds__(1024) void k_histogram(const u64* __restrict__ trace, size_t N, int col_begin, int col_end,
-                                                    u32* __restrict__ hist, int* __restrict__ err) {
-  __shared__ u32 h[32768];
-  const u32 half = blockIdx.y;
-  for (int b = threadIdx.x; b < 32768; b += blockDim.x) h[b] = 0;
-  __syncthreads();
-  const size_t total = (size_t)(col_end - col_begin) * N;
-  const size_t per = (total + gridDim.x - 1) / gridDim.x;
-  const size_t lo = (size_t)blockIdx.x * per, hi = min(total, lo + per);
-  const u64* src = trace + (size_t)col_begin * N;
-  const int lane = threadIdx.x & 63;
-  for (size_t base = lo; base < hi; base += blockDim.x) {
-    size_t i = base + threadIdx.x;
-    u64 v = i < hi ? src[i] : ~0ULL;
-    if (i < hi && v >= 65536) atomicCAS(err, 0, BN254S_E_INTERNAL);
-    bool active = i < hi && (v >> 15) == half;
-    u32 bin = (u32)v & 32767;
-#pragma unroll
-    for (int r = 0; r < 2; r++) {
-      unsigned long long m = __ballot(active);
-      if (m == 0) break;
-      int leader = __ffsll((long long)m) - 1;
-      u32 lv = __shfl(bin, leader);
-      bool same = active && bin == lv;
-      unsigned long long ms = __ballot(same);
-      if (lane == leader) atomicAdd(&h[lv], (u32)__popcll(ms));
-      active = active && !same;
-    }
-    if (active) atomicAdd(&h[bin], 1u);
-  }
-  __syncthreads();
-  for (int b = threadIdx.x; b < 32768; b += blockDim.x) {
-    u32 cnt = h[b];
-    if (cnt) atomicAdd(&hist[half * 32768 + b], cnt);
-  }
-}
-__global__ __launch_bounds__(256) void k_range_columns(u64* __restrict__ trace, size_t N, int freq_col, int range_col,
-                                                       const u32* __restrict__ hist) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= N) return;
-  trace[(size_t)range_col * N + i] = i < 65536 ? i : 65535;
-  trace[(size_t)freq_col * N + i] = i < 65536 ? (u64)hist[i] : 0;
-}
-
 // ---- final outputs: s*x + offset = S_255 in canonical affine form ------------------------------------------
 __global__ void k_g1_outputs(const u64* __restrict__ scalars, int n, const u64* __restrict__ px, const u64* __restrict__ py,
                              const u64* __restrict__ zi, u64* __restrict__ out8) {
@@ -460,22 +351,13 @@ int g1_generate_trace_device(const u64* d_scalars, const u64* d_x, const u64* d_
   u64* rf = deninv + 4 * nrows;
   u32* hist = (u32*)(rf + 1024);
   if (nrows < N) hipMemsetAsync(d_trace, 0, (size_t)G1_W * N * 8, st);
-  hipMemsetAsync(hist, 0, 65536 * 4, st);
-  k_round_flag_table<<<2, 256, 0, st>>>(rf);
+  launch_round_flag_table(rf, st);
   k_g1_chain<<<(unsigned)((n + 63) / 64), 64, 0, st>>>(d_scalars, d_x, d_off, (int)n, px, py, pz, d_err);
-  const int CH = 8;
-  {
-    size_t threads = (cnt + CH - 1) / CH;
-    k_fq_batch_inv<CH><<<(unsigned)((threads + 63) / 64), 64, 0, st>>>(pz, zi, cnt);
-  }
+  launch_fq_batch_inv(pz, zi, cnt, st);
   k_g1_row_den<<<(unsigned)((nrows + 63) / 64), 64, 0, st>>>(d_scalars, (int)n, px, py, zi, den);
-  {
-    size_t threads = (nrows + CH - 1) / CH;
-    k_fq_batch_inv<CH><<<(unsigned)((threads + 63) / 64), 64, 0, st>>>(den, deninv, nrows);
-  }
+  launch_fq_batch_inv(den, deninv, nrows, st);
   k_g1_rows<<<(unsigned)((nrows + 63) / 64), 64, 0, st>>>(d_scalars, (int)n, px, py, zi, deninv, rf, d_trace, N, d_err);
-  k_histogram<<<dim3(128, 2), 1024, 0, st>>>(d_trace, N, G1_RC_BEGIN, G1_RC_END, hist, d_err);
-  k_range_columns<<<(unsigned)((N + 255) / 256), 256, 0, st>>>(d_trace, N, G1_COL_FREQ, G1_COL_RANGE, hist);
+  launch_range_columns(d_trace, N, G1_RC_BEGIN, G1_RC_END, G1_COL_FREQ, G1_COL_RANGE, hist, d_err, st);
   if (d_outputs) k_g1_outputs<<<(unsigned)((n + 63) / 64), 64, 0, st>>>(d_scalars, (int)n, px, py, zi, d_outputs);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }

@@ -1,0 +1,432 @@
+// G2 scalar-multiplication and Fq-exponentiation STARKs: trace generation on the GPU.
+//
+// Replaces, for G2: G2ScalarMulStark::generate_trace / generate_one_set (src/starks/curves/g2/scalar_mul_stark.rs:55-213,
+// the textual twin of the G1 file), generate_g2_add (src/starks/curves/g2/add.rs:59-130),
+// generate_is_ext_modulus_zero / generate_ext_modulus_zero (g2/ext/is_modulus_zero.rs:30-46, ext/modulus_zero.rs:38-46)
+// and the Fq2 limb-polynomial helpers (g2/ext/{mul,add,sub,convert}.rs);
+// for Fq exp: FqExpStark::generate_trace / generate_one_set (src/starks/fields/exp_stark.rs:53-206) and
+// generate_fq_mul (src/starks/fields/mul.rs:22-40).
+// Same structure as trace_g1.hip: a sequential inversion-free chain per instance, Montgomery batch inversion,
+// then one lane per trace row.
+#include "trace_common.h"
+#include "trace_g2fq.h"
+
+// ======================================== G2 ==================================================================
+struct Soa2 {  // an Fq2 SoA vector = two Fq SoA vectors
+  u64 *c0, *c1;
+};
+__device__ __forceinline__ fq2 ld_fq2(const Soa2& v, size_t cnt, size_t e) {
+  fq2 r;
+  r.c0 = ld_fq(v.c0, cnt, e);
+  r.c1 = ld_fq(v.c1, cnt, e);
+  return r;
+}
+__device__ __forceinline__ void st_fq2(const Soa2& v, size_t cnt, size_t e, const fq2& x) {
+  st_fq(v.c0, cnt, e, x.c0);
+  st_fq(v.c1, cnt, e, x.c1);
+}
+__device__ __forceinline__ fq2 fq2_from_canonical(const u64* w) {
+  fq2 r;
+  r.c0 = fq_from_canonical(w);
+  r.c1 = fq_from_canonical(w + 4);
+  return r;
+}
+
+__global__ __launch_bounds__(64) void k_g2_chain(const u64* __restrict__ scalars, const u64* __restrict__ xs,
+                                                 const u64* __restrict__ offs, int n, Soa2 px, Soa2 py, Soa2 pz, u64* __restrict__ znorm,
+                                                 int* __restrict__ err) {
+  int inst = blockIdx.x * blockDim.x + threadIdx.x;
+  if (inst >= n) return;
+  size_t cnt = (size_t)NPTS * n;
+  u64 s[4];
+  for (int i = 0; i < 4; i++) s[i] = scalars[4 * inst + i];
+  g2j S, D;
+  D.x = fq2_from_canonical(xs + 16 * inst);
+  D.y = fq2_from_canonical(xs + 16 * inst + 8);
+  D.z = fq2_one();
+  S.x = fq2_from_canonical(offs + 16 * inst);
+  S.y = fq2_from_canonical(offs + 16 * inst + 8);
+  S.z = fq2_one();
+  auto store = [&](int pt, const g2j& p) {
+    size_t e = (size_t)pt * n + inst;
+    st_fq2(px, cnt, e, p.x);
+    st_fq2(py, cnt, e, p.y);
+    st_fq2(pz, cnt, e, p.z);
+    st_fq(znorm, cnt, e, fq2_norm(p.z));
+  };
+  store(0, S);
+  for (int k = 0; k < 256; k++) {
+    g2j C;
+    int rc = g2_add(S, D, C);
+    if (rc == 2) atomicCAS(err, 0, BN254S_E_INVALID_POINT);
+    store(1 + k, C);
+    store(257 + k, D);
+    if ((s[k >> 6] >> (k & 63)) & 1) S = C;
+    D = g2_double(D);
+  }
+  store(513, D);
+}
+
+struct Aff2 {
+  fq2 x, y;
+};
+__device__ __forceinline__ Aff2 affine_pt2(const Soa2& px, const Soa2& py, const Soa2& pz, const u64* zni, size_t cnt, size_t e) {
+  fq2 zi = fq2_inv_from_norm_inv(ld_fq2(pz, cnt, e), ld_fq(zni, cnt, e));
+  fq2 z2 = fq2_sqr(zi);
+  Aff2 r;
+  r.x = fq2_mul(ld_fq2(px, cnt, e), z2);
+  r.y = fq2_mul(fq2_mul(ld_fq2(py, cnt, e), z2), zi);
+  return r;
+}
+
+// per row: inv-input slots [0] = norm(den), [1] = dx.c0, [2] = dx.c1  (each an Fq SoA vector of nrows)
+__global__ __launch_bounds__(64) void k_g2_row_den(const u64* __restrict__ scalars, int n, Soa2 px, Soa2 py, Soa2 pz,
+                                                   const u64* __restrict__ zni, u64* __restrict__ inv_in) {
+  size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t nrows = (size_t)n * 512;
+  if (r >= nrows) return;
+  int inst = (int)(r >> 9), row = (int)(r & 511), k = row >> 1;
+  size_t cnt = (size_t)NPTS * n;
+  u64 s[4];
+  for (int i = 0; i < 4; i++) s[i] = scalars[4 * inst + i];
+  fq2 den, dx = fq2_zero();
+  if ((row & 1) == 0) {
+    Aff2 a = affine_pt2(px, py, pz, zni, cnt, (size_t)sum_point(s, k) * n + inst);
+    Aff2 b = affine_pt2(px, py, pz, zni, cnt, (size_t)(257 + k) * n + inst);
+    dx = fq2_sub(b.x, a.x);
+    den = fq2_is_zero(dx) ? fq2_dbl(a.y) : dx;
+  } else {
+    Aff2 a = affine_pt2(px, py, pz, zni, cnt, (size_t)(257 + k) * n + inst);
+    den = fq2_dbl(a.y);
+  }
+  st_fq(inv_in, 3 * nrows, r, fq2_norm(den));
+  st_fq(inv_in, 3 * nrows, nrows + r, dx.c0);
+  st_fq(inv_in, 3 * nrows, 2 * nrows + r, dx.c1);
+}
+
+// out[i] = coefficient polynomials of the Fq2 limb product (g2/ext/mul.rs:14-32)
+__device__ __forceinline__ void ext_mul_c0(const int* x0, const int* x1, const int* y0, const int* y1, long long* out) {
+  long long t[31];
+  pol_mul16(x0, y0, out);
+  pol_mul16(x1, y1, t);
+#pragma unroll
+  for (int i = 0; i < 31; i++) out[i] -= t[i];
+}
+__device__ __forceinline__ void ext_mul_c1(const int* x0, const int* x1, const int* y0, const int* y1, long long* out) {
+  long long t[31];
+  pol_mul16(x0, y1, out);
+  pol_mul16(x1, y0, t);
+#pragma unroll
+  for (int i = 0; i < 31; i++) out[i] += t[i];
+}
+
+__global__ __launch_bounds__(64) void k_g2_rows(const u64* __restrict__ scalars, int n, Soa2 px, Soa2 py, Soa2 pz,
+                                                const u64* __restrict__ zni, const u64* __restrict__ inv_out,
+                                                const u64* __restrict__ rf_tbl, u64* __restrict__ trace, size_t N,
+                                                int* __restrict__ err) {
+  typedef G2L L;
+  size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t nrows = (size_t)n * 512;
+  if (r >= nrows) return;
+  const int inst = (int)(r >> 9), row = (int)(r & 511), k = row >> 1;
+  const bool adding = (row & 1) == 0;
+  const size_t cnt = (size_t)NPTS * n;
+  u64 s[4];
+  for (int i = 0; i < 4; i++) s[i] = scalars[4 * inst + i];
+  const bool bitk = (s[k >> 6] >> (k & 63)) & 1;
+  Aff2 a, b, c, sum, dbl;
+  if (adding) {
+    a = affine_pt2(px, py, pz, zni, cnt, (size_t)sum_point(s, k) * n + inst);
+    b = affine_pt2(px, py, pz, zni, cnt, (size_t)(257 + k) * n + inst);
+    c = affine_pt2(px, py, pz, zni, cnt, (size_t)(1 + k) * n + inst);
+    dbl = b;
+    sum = bitk ? c : a;
+  } else {
+    a = affine_pt2(px, py, pz, zni, cnt, (size_t)(257 + k) * n + inst);
+    b = a;
+    c = affine_pt2(px, py, pz, zni, cnt, (size_t)(258 + k) * n + inst);
+    dbl = c;
+    sum = affine_pt2(px, py, pz, zni, cnt, (size_t)sum_point(s, k + 1) * n + inst);
+  }
+  const fq2 dxm = fq2_sub(b.x, a.x);
+  const bool z0 = fq_is_zero(dxm.c0), z1 = fq_is_zero(dxm.c1), x_eq = z0 && z1;
+  const fq2 den = x_eq ? fq2_dbl(a.y) : dxm;
+  const fq2 di = fq2_inv_from_norm_inv(den, ld_fq(inv_out, 3 * nrows, r));
+  fq2 lambda;
+  if (!x_eq) {
+    lambda = fq2_mul(fq2_sub(b.y, a.y), di);  // g2/add.rs:73
+  } else {
+    fq2 xx = fq2_sqr(a.x);
+    lambda = fq2_mul(fq2_add(fq2_dbl(xx), xx), di);  // g2/add.rs:86
+  }
+  const fq inv0 = ld_fq(inv_out, 3 * nrows, nrows + r), inv1 = ld_fq(inv_out, 3 * nrows, 2 * nrows + r);
+
+  auto put = [&](int col, u64 v) { trace[(size_t)col * N + r] = v; };
+  auto put16 = [&](int col, const int* l) {
+#pragma unroll
+    for (int i = 0; i < 16; i++) put(col + i, (u64)l[i]);
+  };
+  int ax0[16], ax1[16], ay0[16], ay1[16], bx0[16], bx1[16], cx0[16], cx1[16], l0[16], l1[16], t0[16], t1[16], u0[16], u1[16];
+  fq_to_limbs(a.x.c0, ax0); fq_to_limbs(a.x.c1, ax1); fq_to_limbs(a.y.c0, ay0); fq_to_limbs(a.y.c1, ay1);
+  fq_to_limbs(b.x.c0, bx0); fq_to_limbs(b.x.c1, bx1); fq_to_limbs(c.x.c0, cx0); fq_to_limbs(c.x.c1, cx1);
+  fq_to_limbs(lambda.c0, l0); fq_to_limbs(lambda.c1, l1);
+  put16(L::A, ax0); put16(L::A + 16, ax1); put16(L::A + 32, ay0); put16(L::A + 48, ay1);
+  put16(L::B, bx0); put16(L::B + 16, bx1);
+  put16(L::C, cx0); put16(L::C + 16, cx1);
+  put16(L::AUX + G2_AUX_LAMBDA, l0); put16(L::AUX + G2_AUX_LAMBDA + 16, l1);
+  fq_to_limbs(dbl.x.c0, t0); put16(L::DOUBLE, t0);
+  fq_to_limbs(dbl.x.c1, t0); put16(L::DOUBLE + 16, t0);
+  fq_to_limbs(dbl.y.c0, t0); put16(L::DOUBLE + 32, t0);
+  fq_to_limbs(dbl.y.c1, t0); put16(L::DOUBLE + 48, t0);
+  fq_to_limbs(sum.x.c0, t0); put16(L::SUM, t0);
+  fq_to_limbs(sum.x.c1, t0); put16(L::SUM + 16, t0);
+  fq_to_limbs(sum.y.c0, t0); put16(L::SUM + 32, t0);
+  fq_to_limbs(sum.y.c1, t0); put16(L::SUM + 48, t0);
+  put(L::AUX + G2_AUX_IS_X_EQ, x_eq);
+  put(L::AUX + G2_AUX_IS_C0_ZERO, z0);
+  put(L::AUX + G2_AUX_IS_C1_ZERO, z1);
+  put(L::AUX + G2_AUX_IS_X_EQ_FILTER, x_eq);
+
+  long long diff[31];
+  int dx0[16], dx1[16];
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    dx0[i] = bx0[i] - ax0[i];
+    dx1[i] = bx1[i] - ax1[i];
+  }
+  // is_modulus_zero witnesses of delta_x.c0 and delta_x.c1 (ext/is_modulus_zero.rs:35-36)
+  fq_to_limbs(inv0, t0);
+  put16(L::AUX + G2_AUX_C0_AUX, t0);
+  pol_mul16(dx0, t0, diff);
+  diff[0] += (long long)z0 - 1;
+  gen_modulus_zero(diff, trace, N, r, L::AUX + G2_AUX_C0_AUX + 16, err);
+  fq_to_limbs(inv1, t0);
+  put16(L::AUX + G2_AUX_C1_AUX, t0);
+  pol_mul16(dx1, t0, diff);
+  diff[0] += (long long)z1 - 1;
+  gen_modulus_zero(diff, trace, N, r, L::AUX + G2_AUX_C1_AUX + 16, err);
+  // lambda witness
+  fq_to_limbs(b.y.c0, t0);  // b.y
+  fq_to_limbs(b.y.c1, t1);
+  put16(L::B + 32, t0);
+  put16(L::B + 48, t1);
+  if (!x_eq) {
+    ext_mul_c0(l0, l1, dx0, dx1, diff);
+#pragma unroll
+    for (int i = 0; i < 16; i++) diff[i] -= (long long)(t0[i] - ay0[i]);
+    gen_modulus_zero(diff, trace, N, r, L::AUX + G2_AUX_LAMBDA_AUX, err);
+    ext_mul_c1(l0, l1, dx0, dx1, diff);
+#pragma unroll
+    for (int i = 0; i < 16; i++) diff[i] -= (long long)(t1[i] - ay1[i]);
+    gen_modulus_zero(diff, trace, N, r, L::AUX + G2_AUX_LAMBDA_AUX + 80, err);
+  } else {
+    long long xx[31];
+    ext_mul_c0(l0, l1, ay0, ay1, diff);
+    ext_mul_c0(ax0, ax1, ax0, ax1, xx);
+#pragma unroll
+    for (int i = 0; i < 31; i++) diff[i] = 2 * diff[i] - 3 * xx[i];
+    gen_modulus_zero(diff, trace, N, r, L::AUX + G2_AUX_LAMBDA_AUX, err);
+    ext_mul_c1(l0, l1, ay0, ay1, diff);
+    ext_mul_c1(ax0, ax1, ax0, ax1, xx);
+#pragma unroll
+    for (int i = 0; i < 31; i++) diff[i] = 2 * diff[i] - 3 * xx[i];
+    gen_modulus_zero(diff, trace, N, r, L::AUX + G2_AUX_LAMBDA_AUX + 80, err);
+  }
+  // x witness: lambda^2 - (a.x + b.x + c.x)
+  ext_mul_c0(l0, l1, l0, l1, diff);
+#pragma unroll
+  for (int i = 0; i < 16; i++) diff[i] -= (long long)(ax0[i] + bx0[i] + cx0[i]);
+  gen_modulus_zero(diff, trace, N, r, L::AUX + G2_AUX_X_AUX, err);
+  ext_mul_c1(l0, l1, l0, l1, diff);
+#pragma unroll
+  for (int i = 0; i < 16; i++) diff[i] -= (long long)(ax1[i] + bx1[i] + cx1[i]);
+  gen_modulus_zero(diff, trace, N, r, L::AUX + G2_AUX_X_AUX + 80, err);
+  // y witness: lambda*(c.x - a.x) + c.y + a.y
+  fq_to_limbs(c.y.c0, t0);
+  fq_to_limbs(c.y.c1, t1);
+  put16(L::C + 32, t0);
+  put16(L::C + 48, t1);
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    u0[i] = cx0[i] - ax0[i];
+    u1[i] = cx1[i] - ax1[i];
+  }
+  ext_mul_c0(l0, l1, u0, u1, diff);
+#pragma unroll
+  for (int i = 0; i < 16; i++) diff[i] += (long long)(t0[i] + ay0[i]);
+  gen_modulus_zero(diff, trace, N, r, L::AUX + G2_AUX_Y_AUX, err);
+  ext_mul_c1(l0, l1, u0, u1, diff);
+#pragma unroll
+  for (int i = 0; i < 16; i++) diff[i] += (long long)(t1[i] + ay1[i]);
+  gen_modulus_zero(diff, trace, N, r, L::AUX + G2_AUX_Y_AUX + 80, err);
+
+  for (int i = 0; i < 256; i++) {
+    int src = (i + k) & 255;
+    put(L::BITS + i, (s[src >> 6] >> (src & 63)) & 1);
+  }
+  put(L::FLAGS + 0, row == 0);
+  put(L::FLAGS + 1, row == 511);
+  put(L::FLAGS + 2, (u64)row);
+  put(L::FLAGS + 3, rf_tbl[row]);
+  put(L::FLAGS + 4, rf_tbl[512 + row]);
+  put(L::TIMESTAMP, (u64)inst);
+  put(L::IS_ADDING, adding ? 1 : 0);
+  put(L::IDNL, adding ? 0 : (row == 511 ? 0 : 1));
+  put(L::FILTER, 1);
+}
+
+__global__ void k_g2_outputs(const u64* __restrict__ scalars, int n, Soa2 px, Soa2 py, Soa2 pz, const u64* __restrict__ zni,
+                             u64* __restrict__ out16) {
+  int inst = blockIdx.x * blockDim.x + threadIdx.x;
+  if (inst >= n) return;
+  u64 s[4];
+  for (int i = 0; i < 4; i++) s[i] = scalars[4 * inst + i];
+  Aff2 p = affine_pt2(px, py, pz, zni, (size_t)NPTS * n, (size_t)sum_point(s, 256) * n + inst);
+  fq v[4] = {fq_to_canonical(p.x.c0), fq_to_canonical(p.x.c1), fq_to_canonical(p.y.c0), fq_to_canonical(p.y.c1)};
+  for (int j = 0; j < 4; j++)
+    for (int i = 0; i < 4; i++) out16[16 * inst + 4 * j + i] = v[j].l[i];
+}
+
+size_t g2_trace_scratch_words(size_t n) {
+  size_t cnt = (size_t)NPTS * n, nrows = n * 512;
+  return 4 * cnt * 8 /* px py pz (2 each) + znorm + zni */ + 2 * 4 * 3 * nrows /* inv in/out */ + 1024 + 65536 / 2;
+}
+
+int g2_generate_trace_device(const u64* d_scalars, const u64* d_x, const u64* d_off, size_t n, u64* d_trace, size_t N,
+                             u64* d_scratch, u64* d_outputs, int* d_err, hipStream_t st) {
+  size_t cnt = (size_t)NPTS * n, nrows = n * 512;
+  u64* p = d_scratch;
+  auto take = [&](size_t words) {
+    u64* r = p;
+    p += words;
+    return r;
+  };
+  Soa2 px{take(4 * cnt), take(4 * cnt)}, py{take(4 * cnt), take(4 * cnt)}, pz{take(4 * cnt), take(4 * cnt)};
+  u64* znorm = take(4 * cnt);
+  u64* zni = take(4 * cnt);
+  u64* inv_in = take(4 * 3 * nrows);
+  u64* inv_out = take(4 * 3 * nrows);
+  u64* rf = take(1024);
+  u32* hist = (u32*)take(65536 / 2);
+  if (nrows < N) hipMemsetAsync(d_trace, 0, (size_t)G2L::W * N * 8, st);
+  launch_round_flag_table(rf, st);
+  k_g2_chain<<<(unsigned)((n + 63) / 64), 64, 0, st>>>(d_scalars, d_x, d_off, (int)n, px, py, pz, znorm, d_err);
+  launch_fq_batch_inv(znorm, zni, cnt, st);
+  k_g2_row_den<<<(unsigned)((nrows + 63) / 64), 64, 0, st>>>(d_scalars, (int)n, px, py, pz, zni, inv_in);
+  launch_fq_batch_inv(inv_in, inv_out, 3 * nrows, st);
+  k_g2_rows<<<(unsigned)((nrows + 63) / 64), 64, 0, st>>>(d_scalars, (int)n, px, py, pz, zni, inv_out, rf, d_trace, N, d_err);
+  launch_range_columns(d_trace, N, G2L::RC_BEGIN, G2L::RC_END, G2L::FREQ, G2L::RANGE, hist, d_err, st);
+  if (d_outputs) k_g2_outputs<<<(unsigned)((n + 63) / 64), 64, 0, st>>>(d_scalars, (int)n, px, py, pz, zni, d_outputs);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// ======================================== Fq exp ==============================================================
+// table per instance: 0 = one, 1+k = C_k = P_{k-1} * x^(2^k), 257+k = x^(2^k)
+__global__ __launch_bounds__(64) void k_fq_chain(const u64* __restrict__ scalars, const u64* __restrict__ xs, int n,
+                                                 u64* __restrict__ tab) {
+  int inst = blockIdx.x * blockDim.x + threadIdx.x;
+  if (inst >= n) return;
+  size_t cnt = (size_t)NPTS * n;
+  u64 s[4];
+  for (int i = 0; i < 4; i++) s[i] = scalars[4 * inst + i];
+  fq sq = fq_from_canonical(xs + 4 * inst), prod = fq_one();
+  st_fq(tab, cnt, inst, prod);
+  for (int k = 0; k < 256; k++) {
+    fq c = fq_mul(prod, sq);
+    st_fq(tab, cnt, (size_t)(1 + k) * n + inst, c);
+    st_fq(tab, cnt, (size_t)(257 + k) * n + inst, sq);
+    if ((s[k >> 6] >> (k & 63)) & 1) prod = c;
+    sq = fq_sqr(sq);
+  }
+  st_fq(tab, cnt, (size_t)513 * n + inst, sq);
+}
+
+__global__ __launch_bounds__(64) void k_fq_rows(const u64* __restrict__ scalars, int n, const u64* __restrict__ tab,
+                                                const u64* __restrict__ rf_tbl, u64* __restrict__ trace, size_t N,
+                                                int* __restrict__ err) {
+  typedef FQL L;
+  size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t nrows = (size_t)n * 512;
+  if (r >= nrows) return;
+  const int inst = (int)(r >> 9), row = (int)(r & 511), k = row >> 1;
+  const bool mul_step = (row & 1) == 0;
+  const size_t cnt = (size_t)NPTS * n;
+  u64 s[4];
+  for (int i = 0; i < 4; i++) s[i] = scalars[4 * inst + i];
+  const bool bitk = (s[k >> 6] >> (k & 63)) & 1;
+  fq a, b, c, square, product;
+  if (mul_step) {
+    a = ld_fq(tab, cnt, (size_t)sum_point(s, k) * n + inst);
+    b = ld_fq(tab, cnt, (size_t)(257 + k) * n + inst);
+    c = ld_fq(tab, cnt, (size_t)(1 + k) * n + inst);
+    square = b;
+    product = bitk ? c : a;
+  } else {
+    a = ld_fq(tab, cnt, (size_t)(257 + k) * n + inst);
+    b = a;
+    c = ld_fq(tab, cnt, (size_t)(258 + k) * n + inst);
+    square = c;
+    product = ld_fq(tab, cnt, (size_t)sum_point(s, k + 1) * n + inst);
+  }
+  auto put = [&](int col, u64 v) { trace[(size_t)col * N + r] = v; };
+  int al[16], bl[16], cl[16], t[16];
+  fq_to_limbs(a, al);
+  fq_to_limbs(b, bl);
+  fq_to_limbs(c, cl);
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    put(L::A + i, al[i]);
+    put(L::B + i, bl[i]);
+    put(L::C + i, cl[i]);
+  }
+  fq_to_limbs(square, t);
+#pragma unroll
+  for (int i = 0; i < 16; i++) put(L::DOUBLE + i, t[i]);
+  fq_to_limbs(product, t);
+#pragma unroll
+  for (int i = 0; i < 16; i++) put(L::SUM + i, t[i]);
+  long long diff[31];
+  pol_mul16(al, bl, diff);  // a*b - c  (fields/mul.rs:34-38)
+#pragma unroll
+  for (int i = 0; i < 16; i++) diff[i] -= (long long)cl[i];
+  gen_modulus_zero(diff, trace, N, r, L::AUX, err);
+  for (int i = 0; i < 256; i++) {
+    int src = (i + k) & 255;
+    put(L::BITS + i, (s[src >> 6] >> (src & 63)) & 1);
+  }
+  put(L::FLAGS + 0, row == 0);
+  put(L::FLAGS + 1, row == 511);
+  put(L::FLAGS + 2, (u64)row);
+  put(L::FLAGS + 3, rf_tbl[row]);
+  put(L::FLAGS + 4, rf_tbl[512 + row]);
+  put(L::TIMESTAMP, (u64)inst);
+  put(L::IS_ADDING, mul_step ? 1 : 0);
+  put(L::IDNL, mul_step ? 0 : (row == 511 ? 0 : 1));
+  put(L::FILTER, 1);
+}
+
+__global__ void k_fq_outputs(const u64* __restrict__ scalars, int n, const u64* __restrict__ tab, u64* __restrict__ out4) {
+  int inst = blockIdx.x * blockDim.x + threadIdx.x;
+  if (inst >= n) return;
+  u64 s[4];
+  for (int i = 0; i < 4; i++) s[i] = scalars[4 * inst + i];
+  fq v = fq_to_canonical(ld_fq(tab, (size_t)NPTS * n, (size_t)sum_point(s, 256) * n + inst));
+  for (int i = 0; i < 4; i++) out4[4 * inst + i] = v.l[i];
+}
+
+size_t fq_trace_scratch_words(size_t n) { return 4 * (size_t)NPTS * n + 1024 + 65536 / 2; }
+
+int fq_generate_trace_device(const u64* d_scalars, const u64* d_x, size_t n, u64* d_trace, size_t N, u64* d_scratch,
+                             u64* d_outputs, int* d_err, hipStream_t st) {
+  size_t cnt = (size_t)NPTS * n, nrows = n * 512;
+  u64* tab = d_scratch;
+  u64* rf = tab + 4 * cnt;
+  u32* hist = (u32*)(rf + 1024);
+  if (nrows < N) hipMemsetAsync(d_trace, 0, (size_t)FQL::W * N * 8, st);
+  launch_round_flag_table(rf, st);
+  k_fq_chain<<<(unsigned)((n + 63) / 64), 64, 0, st>>>(d_scalars, d_x, (int)n, tab);
+  k_fq_rows<<<(unsigned)((nrows + 63) / 64), 64, 0, st>>>(d_scalars, (int)n, tab, rf, d_trace, N, d_err);
+  launch_range_columns(d_trace, N, FQL::RC_BEGIN, FQL::RC_END, FQL::FREQ, FQL::RANGE, hist, d_err, st);
+  if (d_outputs) k_fq_outputs<<<(unsigned)((n + 63) / 64), 64, 0, st>>>(d_scalars, (int)n, tab, d_outputs);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}

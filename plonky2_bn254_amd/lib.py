@@ -43,8 +43,10 @@ def load_library():
     lib.bn254s_ctx_destroy.argtypes = [vp]
     lib.bn254s_last_error.argtypes = [vp]
     lib.bn254s_last_error.restype = C.c_char_p
-    for name in ("bn254s_prove_g1", "bn254s_prove_g2", "bn254s_prove_fq_exp"):
+    for name in ("bn254s_prove_g1", "bn254s_prove_g2"):
         getattr(lib, name).argtypes = [vp, C.POINTER(Params), vp, vp, vp, C.c_size_t, C.POINTER(vp)]
+    lib.bn254s_prove_fq_exp.argtypes = [vp, C.POINTER(Params), vp, vp, C.c_size_t, C.POINTER(vp)]
+    lib.bn254s_generate_trace.argtypes = [vp, C.c_int, vp, vp, vp, C.c_size_t, C.c_uint32, vp, vp]
     lib.bn254s_prove_g1_batch.argtypes = [vp, C.POINTER(Params), vp, vp, vp, C.c_size_t, C.c_size_t, C.POINTER(vp)]
     lib.bn254s_proof_words.argtypes = [vp, C.POINTER(U64P), C.POINTER(C.c_size_t)]
     lib.bn254s_proof_outputs.argtypes = [vp, C.POINTER(U64P), C.POINTER(C.c_size_t)]
@@ -132,6 +134,22 @@ class Context:
                                               C.byref(out)), "bn254s_prove_g1")
         return Proof(self._lib, out)
 
+    def prove_g2(self, scalars, x, offset, params: Optional[Params] = None) -> Proof:
+        """G2 scalar multiplications (points as 16 words x.c0, x.c1, y.c0, y.c1): run_once of G2StarkProofGenerator."""
+        params = params or default_params()
+        out = C.c_void_p()
+        self._check(self._lib.bn254s_prove_g2(self._h, C.byref(params), _ptr(scalars), _ptr(x), _ptr(offset),
+                                              scalars.shape[0], C.byref(out)), "bn254s_prove_g2")
+        return Proof(self._lib, out)
+
+    def prove_fq_exp(self, scalars, x, params: Optional[Params] = None) -> Proof:
+        """Fq exponentiations x^s: run_once of FqStarkProofGenerator (src/generators/fq/stark_proof.rs:135-178)."""
+        params = params or default_params()
+        out = C.c_void_p()
+        self._check(self._lib.bn254s_prove_fq_exp(self._h, C.byref(params), _ptr(scalars), _ptr(x), scalars.shape[0],
+                                                  C.byref(out)), "bn254s_prove_fq_exp")
+        return Proof(self._lib, out)
+
     def prove_g1_batch(self, scalars, x, offset, per_proof=128, params: Optional[Params] = None, keep=True):
         params = params or default_params()
         n = scalars.shape[0]
@@ -162,6 +180,18 @@ class Context:
         st = np.ascontiguousarray(states, dtype=np.uint64).copy()
         self._check(self._lib.bn254s_poseidon_permute(self._h, _ptr(st), st.shape[0]), "bn254s_poseidon_permute")
         return st
+
+    def generate_trace(self, kind, scalars, x, offset=None, min_rows_log2=16):
+        """kind 0 = G1, 1 = G2, 2 = Fq exp.  Returns (trace[W, rows], outputs[n, 8|16|4])."""
+        width, pw = {0: (781, 8), 1: (1295, 16), 2: (427, 4)}[kind]
+        n = scalars.shape[0]
+        rows = max(1 << min_rows_log2, 512 * n)
+        rows = 1 << (rows - 1).bit_length()
+        trace = np.zeros((width, rows), np.uint64)
+        outs = np.zeros((n, pw), np.uint64)
+        self._check(self._lib.bn254s_generate_trace(self._h, kind, _ptr(scalars), _ptr(x), _ptr(offset), n, min_rows_log2,
+                                                    _ptr(trace), _ptr(outs)), "bn254s_generate_trace")
+        return trace, outs
 
     def g1_generate_trace(self, scalars, x, offset, min_rows_log2=16, width=781):
         n = scalars.shape[0]

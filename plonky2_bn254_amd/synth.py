@@ -153,3 +153,94 @@ def g1_inputs(n: int, seed: int = 0x706C6F6E6B7932):
 
 def words_to_int(w) -> int:
     return sum(int(v) << (64 * i) for i, v in enumerate(w))
+
+
+# ---- Fq2 = Fq[u]/(u^2+1) and G2 (y^2 = x^3 + b2) over Python ints ---------------------------------------
+G2_B = (19485874751759354771024239261021720505790618469301721065564631296452457478373,
+        266929791119991161246907387137283842545076965332900288569378510910307636690)   # src/curves/g2.rs:29-36
+G2_GEN = ((10857046999023057135944570762232829481370756359578518086990519993285655852781,
+           11559732032986387107991004021392285783925812861821192530917403151452391805634),
+          (8495653923123431417604973247489272438418190587263600148770280649306958101930,
+           4082367875863433681332203403145435568316851327593401208105741076214120093531))
+
+
+def f2_add(a, b):
+    return ((a[0] + b[0]) % P, (a[1] + b[1]) % P)
+
+
+def f2_sub(a, b):
+    return ((a[0] - b[0]) % P, (a[1] - b[1]) % P)
+
+
+def f2_mul(a, b):
+    return ((a[0] * b[0] - a[1] * b[1]) % P, (a[0] * b[1] + a[1] * b[0]) % P)
+
+
+def f2_inv(a):
+    n = pow((a[0] * a[0] + a[1] * a[1]) % P, -1, P)
+    return (a[0] * n % P, (-a[1]) * n % P)
+
+
+def g2_add(a, b):
+    """Affine add on the twist (textbook formulas), b != -a."""
+    (x1, y1), (x2, y2) = a, b
+    if x1 != x2:
+        lam = f2_mul(f2_sub(y2, y1), f2_inv(f2_sub(x2, x1)))
+    else:
+        if f2_add(y1, y2) == (0, 0):
+            raise ValueError("point at infinity")
+        lam = f2_mul(f2_mul((3, 0), f2_mul(x1, x1)), f2_inv(f2_mul((2, 0), y1)))
+    x3 = f2_sub(f2_sub(f2_mul(lam, lam), x1), x2)
+    y3 = f2_sub(f2_mul(lam, f2_sub(x1, x3)), y1)
+    return (x3, y3)
+
+
+def g2_mul(k: int, pt):
+    """k * pt (k >= 1) by affine double-and-add; raises on infinity."""
+    acc = None
+    for bit in bin(k)[2:]:
+        if acc is not None:
+            acc = g2_add(acc, acc)
+        if bit == "1":
+            acc = pt if acc is None else g2_add(acc, pt)
+    return acc
+
+
+def g2_scalar_mul_offset(s: int, x, offset):
+    k = s % R_ORDER
+    if k == 0:
+        return offset
+    return g2_add(g2_mul(k, x), offset)
+
+
+def g2_inputs(n: int, seed: int = 0x706C6F6E6B7932 + 3):
+    """(scalars[n,4], x[n,16], offset[n,16]); point = x.c0, x.c1, y.c0, y.c1 (4 words each)."""
+    rng = Xoshiro256ss(seed)
+    scalars = np.zeros((n, 4), dtype=np.uint64)
+    xs = np.zeros((n, 16), dtype=np.uint64)
+    offs = np.zeros((n, 16), dtype=np.uint64)
+    for i in range(n):
+        s = rng.next_u256()
+        k1 = rng.next_u256() % (R_ORDER - 1) + 1
+        k2 = rng.next_u256() % (R_ORDER - 1) + 1
+        x = g2_mul(k1, G2_GEN)
+        off = g2_mul(k2, G2_GEN)
+        scalars[i] = _to_words(s)
+        xs[i] = _to_words(x[0][0]) + _to_words(x[0][1]) + _to_words(x[1][0]) + _to_words(x[1][1])
+        offs[i] = _to_words(off[0][0]) + _to_words(off[0][1]) + _to_words(off[1][0]) + _to_words(off[1][1])
+    return scalars, xs, offs
+
+
+def g2_from_words(w):
+    return ((words_to_int(w[0:4]), words_to_int(w[4:8])), (words_to_int(w[8:12]), words_to_int(w[12:16])))
+
+
+def fq_inputs(n: int, seed: int = 0x706C6F6E6B7932 + 5):
+    """(scalars[n,4], x[n,4]) for the Fq exponentiation STARK: x uniform in [0,p), s any 256-bit value."""
+    rng = Xoshiro256ss(seed)
+    scalars = np.zeros((n, 4), dtype=np.uint64)
+    xs = np.zeros((n, 4), dtype=np.uint64)
+    for i in range(n):
+        scalars[i] = _to_words(rng.next_u256())
+        xs[i] = _to_words(rng.next_u256() % P)
+    return scalars, xs

@@ -193,3 +193,33 @@ def test_g1_trace_satisfies_air_and_layout(oracle):
         exp = synth.g1_scalar_mul_offset(synth.words_to_int(s[i]), (synth.words_to_int(x[i, :4]), synth.words_to_int(x[i, 4:])),
                                          (synth.words_to_int(o[i, :4]), synth.words_to_int(o[i, 4:])))
         assert (synth.words_to_int(outs[i, :4]), synth.words_to_int(outs[i, 4:])) == exp
+
+
+@pytest.mark.parametrize("kind,name,n_constraints", [(1, "g2", 1693), (2, "fq", 770)])
+def test_g2_and_fq_traces_satisfy_their_airs(oracle, kind, name, n_constraints):
+    """G2 scalar-mul (W 1295, 1693 constraints) and Fq-exp (W 427, 770 constraints): generated traces satisfy every
+    constraint on consecutive rows, outputs equal independent big-int arithmetic (the reference asserts the same against
+    ark-bn254: g2/scalar_mul_stark.rs:105-108, exp_stark.rs:98-100)."""
+    g = synth.G2_GEN
+    assert synth.f2_mul(g[1], g[1]) == synth.f2_add(synth.f2_mul(g[0], synth.f2_mul(g[0], g[0])), synth.G2_B)
+    if kind == 1:
+        s, x, o = synth.g2_inputs(2)
+        o[1] = x[1]
+    else:
+        (s, x), o = synth.fq_inputs(2), None
+    tr, outs = oracle_lib.generate_trace(oracle, kind, s, x, o)
+    assert tr.shape[0] == {1: 1295, 2: 427}[kind]
+    rowsT = np.ascontiguousarray(tr.T)
+    alphas = np.array([123456789123456789 % P, 987654321987654321 % P], dtype=np.uint64)
+    accs = np.zeros(2, np.uint64)
+    for r in [0, 1, 2, 3, 510, 511, 512, 513, 1023, 1024, 30000]:
+        n = oracle.orc_eval_constraints(kind, oracle_lib.ptr(rowsT[r]), oracle_lib.ptr(rowsT[(r + 1) % tr.shape[1]]),
+                                        oracle_lib.ptr(alphas), 7, 0, 0, oracle_lib.ptr(accs))
+        assert n == n_constraints
+        assert accs[0] == 0 and accs[1] == 0, (name, r)
+    for i in range(2):
+        si = synth.words_to_int(s[i])
+        if kind == 1:
+            assert synth.g2_from_words(outs[i]) == synth.g2_scalar_mul_offset(si, synth.g2_from_words(x[i]), synth.g2_from_words(o[i]))
+        else:
+            assert synth.words_to_int(outs[i]) == pow(synth.words_to_int(x[i]), si, synth.P)
