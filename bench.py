@@ -87,11 +87,14 @@ def main():
     if world > 1:
         import torch.distributed as dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist_mod.init_process_group(backend="nccl", rank=rank, world_size=world)
+        # BENCH_BACKEND=gloo / BENCH_DEVICE=0 exist only to rehearse the N>1 path on a one-GPU box
+        dist_mod.init_process_group(backend=os.environ.get("BENCH_BACKEND", "nccl"), rank=rank, world_size=world)
         dist = dist_mod
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    ctx = pk.Context(local_rank)
+    dev_id = int(os.environ.get("BENCH_DEVICE", local_rank))
+    torch.cuda.set_device(dev_id)
+    device = torch.device("cuda", dev_id)
+    gather_device = device if os.environ.get("BENCH_BACKEND", "nccl") == "nccl" else torch.device("cpu")
+    ctx = pk.Context(dev_id)
 
     per_rank = INSTANCES_PER_PROOF * PROOFS_PER_STEP
     lo, hi = shard_range(rank, world, per_rank)
@@ -102,7 +105,7 @@ def main():
         proofs = ctx.prove_g1_batch(s, x, o, per_proof=INSTANCES_PER_PROOF)
         caps = caps_of(proofs)
         if dist is not None:
-            caps = gather_caps(caps, dist, device)
+            caps = gather_caps(caps, dist, gather_device)
         return proofs, caps
 
     def sync():
@@ -124,7 +127,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        t = torch.tensor([dt], device=gather_device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -139,6 +142,13 @@ def main():
         # the same stage alone on the GPU (no other stream), after the timed region
         excl_ms = ctx.bench_ntt(W + A, 5)
         excl = ntt_bytes / (excl_ms * 1e-3) / 1e9
+        # HBM traffic of the same six launches from the PMC passes (FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc_ntt.md)
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_ntt.json")) as f:
+                traffic = int(json.load(f)["ntt_stage_traffic_bytes_per_1237_cols"])
+        except Exception:
+            pass
         out = {
             "metric": "G1 scalar-mul STARK proofs/sec (256-bit scalars)",
             "value": round(total_proofs / dt, 3),
@@ -161,7 +171,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "ntt_lde stage = k_ntt_pass1 + k_ntt_pass2 x {iNTT, coset g, coset g*w_2N} "
                                                    "over the 781 trace + 456 aux columns of one proof",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "algorithmic_bytes": ntt_bytes, "ms": round(ntt_ms, 4),
                          "exclusive": {"achieved": round(excl, 1), "frac": round(excl / HBM_PEAK_GBS, 4),
                                        "ms": round(excl_ms, 4),

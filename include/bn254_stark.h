@@ -91,6 +91,10 @@ int bn254s_prove_g1(bn254s_ctx* ctx, const bn254s_params* params, const uint64_t
 int bn254s_prove_g1_batch(bn254s_ctx* ctx, const bn254s_params* params, const uint64_t* scalars, const uint64_t* x,
                           const uint64_t* offset, size_t n_total, size_t per_proof, bn254s_proof** proofs_out);
 
+/* Generic form of the above: kind 0 = G1, 1 = G2 (points 16 words), 2 = Fq exp (x 4 words, offset NULL). */
+int bn254s_prove_batch(bn254s_ctx* ctx, int kind, const bn254s_params* params, const uint64_t* scalars, const uint64_t* x,
+                       const uint64_t* offset, size_t n_total, size_t per_proof, bn254s_proof** proofs_out);
+
 /* Same for G2 (points n x 16 words: x.c0, x.c1, y.c0, y.c1): src/generators/g2/stark_proof.rs:136-179. */
 int bn254s_prove_g2(bn254s_ctx* ctx, const bn254s_params* params, const uint64_t* scalars, const uint64_t* x,
                     const uint64_t* offset, size_t n, bn254s_proof** out);
@@ -117,6 +121,10 @@ int bn254s_commit_values(bn254s_ctx* ctx, const uint64_t* values, size_t ncols, 
 /* Times `iters` runs of the NTT/LDE stage (iNTT + both coset NTTs) on ncols resident columns of 2^16
  * synthetic values; returns average milliseconds per run through *ms (HIP events on the kernels' stream). */
 int bn254s_bench_ntt(bn254s_ctx* ctx, size_t ncols, int iters, float* ms);
+/* PMC calibration: `iters` plain copies of `words` u64 with 8-byte-per-lane loads/stores (known traffic). */
+int bn254s_bench_copy(bn254s_ctx* ctx, size_t words, int iters);
+/* Times the Merkle leaf-hash kernel alone: ncols columns x 2^log_leaves rows of synthetic data, ms per run. */
+int bn254s_bench_leafhash(bn254s_ctx* ctx, size_t ncols, int log_leaves, int iters, float* ms);
 /* Poseidon permutation of `n` 12-word states in place (host buffer). */
 int bn254s_poseidon_permute(bn254s_ctx* ctx, uint64_t* states, size_t n);
 /* Trace generation only: column-major trace[W][rows] copied to the host buffer.

@@ -125,6 +125,49 @@ int bn254s_bench_ntt(bn254s_ctx* c, size_t ncols, int iters, float* ms) {
   return BN254S_OK;
 }
 
+// Calibration kernel for the PMC traffic counters: a plain 8-byte-per-lane copy of `words` u64 (reads and writes
+// words*8 bytes), the same access width as the NTT kernels.
+__global__ void k_copy_u64(const u64* __restrict__ in, u64* __restrict__ out, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = in[i];
+}
+int bn254s_bench_copy(bn254s_ctx* c, size_t words, int iters) {
+  if (!c || words == 0 || iters <= 0) return BN254S_E_INVALID_ARG;
+  HIP_TRY(c, hipSetDevice(c->device));
+  u64* a = c->words("cp.a", words);
+  u64* b = c->words("cp.b", words);
+  if (!a || !b) return BN254S_E_OOM;
+  k_fill_pseudo<<<(unsigned)((words + 255) / 256), 256, 0, c->stream>>>(a, words, 5);
+  for (int i = 0; i < iters; i++) k_copy_u64<<<(unsigned)((words + 255) / 256), 256, 0, c->stream>>>(a, b, words);
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return BN254S_OK;
+}
+
+// Times the leaf-hash kernel alone on `ncols` columns of 2^log_leaves synthetic rows (ms per run).
+int bn254s_bench_leafhash(bn254s_ctx* c, size_t ncols, int log_leaves, int iters, float* ms) {
+  if (!c || !ms || ncols == 0 || iters <= 0 || log_leaves < 4 || log_leaves > 24) return BN254S_E_INVALID_ARG;
+  HIP_TRY(c, hipSetDevice(c->device));
+  size_t n = (size_t)1 << log_leaves;
+  u64* d = c->words("lh.data", ncols * n);
+  u64* t = c->words("lh.tree", 4 * n);
+  if (!d || !t) return BN254S_E_OOM;
+  k_fill_pseudo<<<(unsigned)((ncols * n + 255) / 256), 256, 0, c->stream>>>(d, ncols * n, 77);
+  hipEvent_t e0, e1;
+  HIP_TRY(c, hipEventCreate(&e0));
+  HIP_TRY(c, hipEventCreate(&e1));
+  merkle_leaves(d, 1, n, (int)ncols, log_leaves, t, c->stream);
+  HIP_TRY(c, hipEventRecord(e0, c->stream));
+  for (int i = 0; i < iters; i++) merkle_leaves(d, 1, n, (int)ncols, log_leaves, t, c->stream);
+  HIP_TRY(c, hipEventRecord(e1, c->stream));
+  HIP_TRY(c, hipEventSynchronize(e1));
+  float tt = 0;
+  HIP_TRY(c, hipEventElapsedTime(&tt, e0, e1));
+  *ms = tt / iters;
+  hipEventDestroy(e0);
+  hipEventDestroy(e1);
+  return BN254S_OK;
+}
+
 __global__ void k_poseidon_states(u64* st, size_t n) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;

@@ -557,15 +557,16 @@ int bn254s_prove_g1(bn254s_ctx* c, const bn254s_params* params, const uint64_t* 
   return BN254S_OK;
 }
 
-int bn254s_prove_g1_batch(bn254s_ctx* c, const bn254s_params* params, const uint64_t* scalars, const uint64_t* x,
-                          const uint64_t* off, size_t n_total, size_t per_proof, bn254s_proof** proofs_out) {
-  if (!c || !params || !scalars || !x || !off || !proofs_out || n_total == 0 || per_proof == 0 ||
+int bn254s_prove_batch(bn254s_ctx* c, int kind, const bn254s_params* params, const uint64_t* scalars, const uint64_t* x,
+                       const uint64_t* off, size_t n_total, size_t per_proof, bn254s_proof** proofs_out) {
+  if (!c || kind < 0 || kind > 2 || !params || !scalars || !x || (kind != KIND_FQ && !off) || !proofs_out || n_total == 0 || per_proof == 0 ||
       params->struct_size != sizeof(bn254s_params))
     return BN254S_E_INVALID_ARG;
   const size_t n_proofs = (n_total + per_proof - 1) / per_proof;
+  const size_t PW = point_words(kind);
   for (size_t i = 0; i < n_proofs; i++) proofs_out[i] = nullptr;
   HIP_TRY(c, hipSetDevice(c->device));
-  size_t n_slots = 4;
+  size_t n_slots = 6;
   if (const char* e = getenv("BN254S_SLOTS")) n_slots = std::max(1, atoi(e));
   n_slots = std::min(n_slots, n_proofs);
   for (size_t s = 0; s < n_slots; s++)
@@ -582,7 +583,7 @@ int bn254s_prove_g1_batch(bn254s_ctx* c, const bn254s_params* params, const uint
         if (i >= n_proofs || first_rc.load() != 0) break;
         size_t b = i * per_proof, cnt = std::min(per_proof, n_total - b);
         bn254s_proof* pr = new bn254s_proof();
-        int rc = prove_on_slot(c, *c->slots[s], KIND_G1, *params, scalars + 4 * b, x + 8 * b, off + 8 * b, cnt, pr, errs[s]);
+        int rc = prove_on_slot(c, *c->slots[s], kind, *params, scalars + 4 * b, x + PW * b, off ? off + PW * b : nullptr, cnt, pr, errs[s]);
         if (rc != BN254S_OK) {
           hipStreamSynchronize(c->slots[s]->st);
           delete pr;
@@ -604,6 +605,11 @@ int bn254s_prove_g1_batch(bn254s_ctx* c, const bn254s_params* params, const uint
     return rc;
   }
   return BN254S_OK;
+}
+
+int bn254s_prove_g1_batch(bn254s_ctx* c, const bn254s_params* params, const uint64_t* scalars, const uint64_t* x,
+                          const uint64_t* off, size_t n_total, size_t per_proof, bn254s_proof** proofs_out) {
+  return bn254s_prove_batch(c, KIND_G1, params, scalars, x, off, n_total, per_proof, proofs_out);
 }
 
 static int prove_one(bn254s_ctx* c, int kind, const bn254s_params* params, const uint64_t* scalars, const uint64_t* x,

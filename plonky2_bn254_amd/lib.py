@@ -48,6 +48,7 @@ def load_library():
     lib.bn254s_prove_fq_exp.argtypes = [vp, C.POINTER(Params), vp, vp, C.c_size_t, C.POINTER(vp)]
     lib.bn254s_generate_trace.argtypes = [vp, C.c_int, vp, vp, vp, C.c_size_t, C.c_uint32, vp, vp]
     lib.bn254s_prove_g1_batch.argtypes = [vp, C.POINTER(Params), vp, vp, vp, C.c_size_t, C.c_size_t, C.POINTER(vp)]
+    lib.bn254s_prove_batch.argtypes = [vp, C.c_int, C.POINTER(Params), vp, vp, vp, C.c_size_t, C.c_size_t, C.POINTER(vp)]
     lib.bn254s_proof_words.argtypes = [vp, C.POINTER(U64P), C.POINTER(C.c_size_t)]
     lib.bn254s_proof_outputs.argtypes = [vp, C.POINTER(U64P), C.POINTER(C.c_size_t)]
     lib.bn254s_proof_degree_bits.argtypes = [vp]
@@ -58,6 +59,8 @@ def load_library():
     lib.bn254s_commit_values.argtypes = [vp, vp, C.c_size_t, vp, vp, vp]
     lib.bn254s_bench_ntt.argtypes = [vp, C.c_size_t, C.c_int, C.POINTER(C.c_float)]
     lib.bn254s_poseidon_permute.argtypes = [vp, vp, C.c_size_t]
+    lib.bn254s_bench_copy.argtypes = [vp, C.c_size_t, C.c_int]
+    lib.bn254s_bench_leafhash.argtypes = [vp, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_float)]
     lib.bn254s_g1_generate_trace.argtypes = [vp, vp, vp, vp, C.c_size_t, C.c_uint32, vp, vp]
     _lib = lib
     return lib
@@ -160,6 +163,16 @@ class Context:
         proofs = [Proof(self._lib, C.c_void_p(outs[i])) for i in range(k)]
         return proofs
 
+    def prove_batch(self, kind, scalars, x, offset=None, per_proof=128, params: Optional[Params] = None):
+        """kind 0 = G1, 1 = G2, 2 = Fq exp: n jobs cut into independent 128-instance proofs, pipelined on the GPU."""
+        params = params or default_params()
+        n = scalars.shape[0]
+        k = (n + per_proof - 1) // per_proof
+        outs = (C.c_void_p * k)()
+        self._check(self._lib.bn254s_prove_batch(self._h, kind, C.byref(params), _ptr(scalars), _ptr(x), _ptr(offset), n,
+                                                 per_proof, outs), "bn254s_prove_batch")
+        return [Proof(self._lib, C.c_void_p(outs[i])) for i in range(k)]
+
     # ---- kernel-level entry points ----
     def commit_values(self, values: np.ndarray, want_coeffs=True, want_lde=True):
         ncols, n = values.shape
@@ -174,6 +187,14 @@ class Context:
     def bench_ntt(self, ncols: int, iters: int = 10) -> float:
         ms = C.c_float()
         self._check(self._lib.bn254s_bench_ntt(self._h, ncols, iters, C.byref(ms)), "bn254s_bench_ntt")
+        return ms.value
+
+    def bench_copy(self, words: int, iters: int = 3):
+        self._check(self._lib.bn254s_bench_copy(self._h, words, iters), "bn254s_bench_copy")
+
+    def bench_leafhash(self, ncols: int, log_leaves: int = 17, iters: int = 5) -> float:
+        ms = C.c_float()
+        self._check(self._lib.bn254s_bench_leafhash(self._h, ncols, log_leaves, iters, C.byref(ms)), "bn254s_bench_leafhash")
         return ms.value
 
     def poseidon_permute(self, states: np.ndarray) -> np.ndarray:

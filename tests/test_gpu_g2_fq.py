@@ -92,3 +92,21 @@ def test_g2_full_batch_verifies(gpu_ctx, oracle):
         exp = synth.g2_scalar_mul_offset(synth.words_to_int(s[i]), synth.g2_from_words(x[i]), synth.g2_from_words(o[i]))
         assert synth.g2_from_words(pr.outputs.reshape(-1, 16)[i]) == exp
     print("G2 stage ms:", {k: round(v, 2) for k, v in pr.stage_ms.items()})
+
+
+def test_batches_of_g2_and_fq(gpu_ctx, oracle):
+    """BASELINE configs 3/5 shape in miniature: jobs cut into 128-instance proofs, every proof verifies against its slice."""
+    s, x, o = synth.g2_inputs(130, seed=9)
+    proofs = gpu_ctx.prove_batch(1, s, x, o)
+    assert len(proofs) == 2
+    for i, pr in enumerate(proofs):
+        sl = slice(128 * i, min(128 * (i + 1), 130))
+        rc, msg = oracle_lib.verify(oracle, 1, pr.words, pr.degree_bits, s[sl], x[sl], o[sl])
+        assert rc == 0, (i, msg)
+    s, x = synth.fq_inputs(300, seed=10)
+    proofs = gpu_ctx.prove_batch(2, s, x)
+    assert len(proofs) == 3
+    for i, pr in enumerate(proofs):
+        sl = slice(128 * i, min(128 * (i + 1), 300))
+        rc, msg = oracle_lib.verify(oracle, 2, pr.words, pr.degree_bits, s[sl], x[sl])
+        assert rc == 0, (i, msg)
