@@ -5,6 +5,7 @@
 #include <map>
 #include <cstdio>
 #include <mutex>
+#include <condition_variable>
 #include <hip/hip_runtime.h>
 #include "../../include/bn254_stark.h"
 #include "gl_dev.h"
@@ -54,6 +55,28 @@ struct bn254s_ctx : BufPool {
   // they cannot run faster side by side, and alone they give clean per-kernel timings.  Latency-bound
   // kernels (EC chain, upper Merkle levels, scans, PoW) run outside it and overlap freely.
   std::mutex big_mu;
+  std::condition_variable big_cv;
+  int big_excl = 0, big_shared = 0;  // holders of the exclusive class / of the shared (hash) class
+  // Exclusive sections (NTT, quotient, openings, FRI combine) run alone; the Poseidon leaf-hash kernels of up to
+  // two proofs may run side by side (one 2^17-leaf launch puts only two waves on a SIMD).
+  void big_lock(bool shared) {
+    std::unique_lock<std::mutex> lk(big_mu);
+    if (shared) {
+      big_cv.wait(lk, [&] { return big_excl == 0 && big_shared < 2; });
+      big_shared++;
+    } else {
+      big_cv.wait(lk, [&] { return big_excl == 0 && big_shared == 0; });
+      big_excl = 1;
+    }
+  }
+  void big_unlock(bool shared) {
+    {
+      std::lock_guard<std::mutex> lk(big_mu);
+      if (shared) big_shared--;
+      else big_excl = 0;
+    }
+    big_cv.notify_all();
+  }
   Slot* slot(size_t i) {
     while (slots.size() <= i) {
       Slot* s = new Slot();

@@ -133,9 +133,11 @@ __device__ __forceinline__ u64 mul_w16inv(u64 x) {
 }
 template <int SPAN, int G, int J>
 __device__ __forceinline__ void ibfly(u64* x) {
+  constexpr int E = J * (8 / SPAN);
   u64 a = x[G + J], b = x[G + J + SPAN];
   x[G + J] = gl_add(a, b);
-  x[G + J + SPAN] = mul_w16inv<J * (8 / SPAN)>(gl_sub(a, b));
+  if constexpr (E == 0) x[G + J + SPAN] = gl_sub(a, b);
+  else x[G + J + SPAN] = gl_mul_2exp<96 - 12 * E>(gl_sub(b, a));  // w_16^-E = 2^(192-12E) = -2^(96-12E)
 }
 __device__ __forceinline__ void idft16(u64* x) {  // natural in, X[k] in x[br4(k)], unscaled
 #define BF(SPAN, G, J) ibfly<SPAN, G, J>(x)

@@ -17,16 +17,16 @@ static constexpr u64 GL_EPS = 0xFFFFFFFFULL;
 static constexpr u64 GL_GEN = 0xc65c18b67785d900ULL;       // multiplicative generator = coset shift
 static constexpr u64 GL_POW2_GEN = 0x64fdd1a46201e246ULL;  // element of order 2^32
 
+// a + b: the wrapped case (+2^64 == +EPS) and the ">= p" case (-p) are the same 64-bit operation s + EPS
+// (EPS + p = 2^64), so one add and one select canonicalise both.
 GL_HD u64 gl_add(u64 a, u64 b) {
   u64 s = a + b;
-  if (s < a) s += GL_EPS;       // wrapped: +2^64 == +(2^32-1) mod p; result < p
-  else if (s >= GL_P) s -= GL_P;
-  return s;
+  u64 t = s + GL_EPS;
+  return (s < a || s >= GL_P) ? t : s;
 }
 GL_HD u64 gl_sub(u64 a, u64 b) {
   u64 d = a - b;
-  if (a < b) d -= GL_EPS;  // borrowed 2^64: subtract (2^32-1) more, i.e. add p
-  return d;
+  return (a < b) ? d - GL_EPS : d;  // borrowed 2^64: subtract (2^32-1) more, i.e. add p
 }
 GL_HD u64 gl_neg(u64 a) { return a ? GL_P - a : 0; }
 GL_HD u64 gl_dbl(u64 a) { return gl_add(a, a); }
@@ -39,16 +39,15 @@ GL_HD u64 gl_mulhi(u64 a, u64 b) {
 #endif
 }
 
-// (hi:lo) mod p, canonical.
+// (hi:lo) mod p, canonical.  2^64 = EPS, 2^96 = -1 (mod p).
 GL_HD u64 gl_reduce128(u64 lo, u64 hi) {
   u64 hi_hi = hi >> 32, hi_lo = hi & GL_EPS;
   u64 t0 = lo - hi_hi;
-  if (lo < hi_hi) t0 -= GL_EPS;
+  t0 = (lo < hi_hi) ? t0 - GL_EPS : t0;
   u64 t1 = (hi_lo << 32) - hi_lo;  // hi_lo * (2^32 - 1)
   u64 r = t0 + t1;
-  if (r < t1) r += GL_EPS;
-  if (r >= GL_P) r -= GL_P;
-  return r;
+  u64 r2 = r + GL_EPS;             // wrapped sum (+2^64) and r >= p (-p) are the same correction
+  return (r < t1 || r >= GL_P) ? r2 : r;
 }
 GL_HD u64 gl_mul(u64 a, u64 b) { return gl_reduce128(a * b, gl_mulhi(a, b)); }
 GL_HD u64 gl_sqr(u64 a) { return gl_mul(a, a); }

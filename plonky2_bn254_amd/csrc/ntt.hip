@@ -29,9 +29,13 @@ __device__ __forceinline__ u64 mul_w16(u64 x) {
 }
 template <bool INV, int SPAN, int G, int J>
 __device__ __forceinline__ void bfly16(u64* x) {
+  constexpr int E = J * (8 / SPAN);
+  constexpr int S = E == 0 ? 0 : (!INV ? 12 * E : 192 - 12 * E);  // twiddle = 2^S
   u64 a = x[G + J], b = x[G + J + SPAN];
   x[G + J] = gl_add(a, b);
-  x[G + J + SPAN] = mul_w16<INV, J * (8 / SPAN)>(gl_sub(a, b));
+  // 2^96 = -1: a negative twiddle is folded into the subtraction (b - a) instead of a separate negation
+  if constexpr (S >= 96) x[G + J + SPAN] = gl_mul_2exp<S - 96>(gl_sub(b, a));
+  else x[G + J + SPAN] = gl_mul_2exp<S>(gl_sub(a, b));
 }
 // DIF network: natural-order input, output X[k] ends up in x[bitrev4(k)].
 template <bool INV>

@@ -101,10 +101,11 @@ __global__ __launch_bounds__(256) void k_quotient_chunks(const u64* __restrict__
 struct BigSection {
   bn254s_ctx* c;
   hipStream_t st;
-  BigSection(bn254s_ctx* c_, hipStream_t st_) : c(c_), st(st_) { c->big_mu.lock(); }
+  bool shared;
+  BigSection(bn254s_ctx* c_, hipStream_t st_, bool shared_ = false) : c(c_), st(st_), shared(shared_) { c->big_lock(shared); }
   ~BigSection() {
     hipStreamSynchronize(st);
-    c->big_mu.unlock();
+    c->big_unlock(shared);
   }
 };
 
@@ -255,6 +256,9 @@ static int prove_on_slot(bn254s_ctx* c, Slot& sl, int kind, const bn254s_params&
     ntt_inverse(&c->ntt, d_tvals, d_tcoef, d_tmp, W, st);
     ntt_lde(&c->ntt, d_tcoef, d_tlde, d_tmp, W, st);
     se(ST_TRACE_NTT);
+  }
+  {
+    BigSection big(c, st, true);
     sb(ST_TRACE_MERKLE);
     merkle_leaves(d_tlde, 1, M2, W, log_m2, d_ttree, st);
   }
@@ -290,6 +294,9 @@ static int prove_on_slot(bn254s_ctx* c, Slot& sl, int kind, const bn254s_params&
     ntt_inverse(&c->ntt, d_avals, d_acoef, d_tmp, A, st);
     ntt_lde(&c->ntt, d_acoef, d_alde, d_tmp, A, st);
     se(ST_AUX_NTT);
+  }
+  {
+    BigSection big(c, st, true);
     sb(ST_AUX_MERKLE);
     merkle_leaves(d_alde, 1, M2, A, log_m2, d_atree, st);
   }

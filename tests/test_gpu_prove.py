@@ -88,3 +88,35 @@ def test_batch_matches_single(gpu_ctx):
         sl = slice(128 * i, min(128 * (i + 1), 300))
         single = gpu_ctx.prove_g1(s[sl], x[sl], o[sl])
         assert np.array_equal(pr.words, single.words), i
+
+
+def test_argument_errors(gpu_ctx):
+    """Error behaviour of the ABI (the reference panics; the library returns status codes):
+    empty batch -> INVALID_ARG (-1); more than 128 instances in ONE proof -> UNSUPPORTED (-5, tall proofs are not
+    built yet); min_rows below 2^16 -> INVALID_ARG like the reference's out-of-bounds panic in generate_range_checks."""
+    import plonky2_bn254_amd as pk
+    s, x, o = synth.g1_inputs(2, seed=1)
+    with pytest.raises(RuntimeError, match="-1"):
+        gpu_ctx.prove_g1(s[:0], x[:0], o[:0])
+    s129 = np.repeat(s[:1], 129, axis=0)
+    x129 = np.repeat(x[:1], 129, axis=0)
+    o129 = np.repeat(o[:1], 129, axis=0)
+    with pytest.raises(RuntimeError, match="-5"):
+        gpu_ctx.prove_g1(s129, x129, o129)
+    p = pk.default_params()
+    p.min_rows_log2 = 12
+    with pytest.raises(RuntimeError, match="-5"):
+        gpu_ctx.prove_g1(s, x, o, params=p)
+    # the same context keeps working after errors
+    pr = gpu_ctx.prove_g1(s, x, o)
+    assert pr.words.size == 135841
+
+
+def test_identical_instances_and_repeated_calls_are_deterministic(gpu_ctx):
+    """128 copies of one job (maximally colliding range-check histogram) and two runs byte-compare."""
+    s, x, o = synth.g1_inputs(1, seed=21)
+    s, x, o = (np.repeat(a, 128, axis=0) for a in (s, x, o))
+    a = gpu_ctx.prove_g1(s, x, o)
+    b = gpu_ctx.prove_g1(s, x, o)
+    assert np.array_equal(a.words, b.words)
+    assert np.array_equal(a.outputs.reshape(128, 8), np.repeat(a.outputs.reshape(128, 8)[:1], 128, axis=0))
