@@ -171,7 +171,7 @@ static int prove_on_slot(bn254s_ctx* c, Slot& sl, int kind, const bn254s_params&
   u64* d_alde = mem.words("alde", (size_t)A * M2);
   const size_t trace_scr = kind == KIND_G1 ? g1_trace_scratch_words(n) : kind == KIND_G2 ? g2_trace_scratch_words(n) : fq_trace_scratch_words(n);
   u64* d_scr = mem.words("scratch", std::max(trace_scr, aux_scratch_words(sh, N)));
-  u64* d_q = mem.words("quot", (size_t)(3 * NQ) * N + (size_t)NQ * M2);  // qv, ab, qcoef, qlde
+  u64* d_q = mem.words("quot", (size_t)(3 * NQ) * N + (size_t)NQ * M2 + (size_t)QUOTIENT_MAX_PARTS * 2 * M2);  // qv, ab, qcoef, qlde, partials
   u64* d_tabs = mem.words("tabs", 2 * (size_t)K + 10 * 2 * 80 + 2 * (size_t)(W + A + NQ));
   u64* d_open = mem.words("open", (size_t)(W + A + NQ) * 5);
   // FRI layer values (extension, 2 words) and trees
@@ -211,6 +211,7 @@ static int prove_on_slot(bn254s_ctx* c, Slot& sl, int kind, const bn254s_params&
   u64* d_ab = d_q + (size_t)NQ * N;      // [2][2][N]
   u64* d_qcoef = d_q + (size_t)2 * NQ * N;  // [4][N]
   u64* d_qlde = d_q + (size_t)3 * NQ * N;   // [4][2N]
+  u64* d_qpart = d_qlde + (size_t)NQ * M2;  // [parts][2][2N]
   u64* d_W = d_tabs;
   u64* d_mzt = d_tabs + 2 * (size_t)K;
   u64* d_apow = d_mzt + 10 * 2 * 80;
@@ -322,7 +323,7 @@ static int prove_on_slot(bn254s_ctx* c, Slot& sl, int kind, const bn254s_params&
     BigSection big(c, st);
     sb(ST_QUOTIENT);
     QArgs QA;
-    quotient_fill_args(QA, sh, d_tlde, d_alde, d_W, d_mzt, pt, betas, gammas, log_n, d_qv);
+    quotient_fill_args(QA, sh, d_tlde, d_alde, d_W, d_mzt, pt, betas, gammas, log_n, d_qv, d_qpart);
     if (kind == KIND_G1) g1_quotient_launch(QA, sh, st);
     else if (kind == KIND_G2) g2_quotient_launch(QA, sh, st);
     else fq_quotient_launch(QA, sh, st);

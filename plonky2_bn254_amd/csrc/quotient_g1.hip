@@ -19,107 +19,121 @@ static constexpr int G1_K_AIR = 1111;
 // first constraint index of the five eval_modulus_zero blocks inside eval_g1_add
 static constexpr int G1_MZ_E0[5] = {0, 50, 83, 132, 165};
 
-__global__ __launch_bounds__(256) void k_quotient_g1(QArgs A, StarkShape sh) {
+// Parts 0..4: the five eval_modulus_zero blocks of eval_g1_add (each with the small groups emitted next to it);
+// part 5: the schedule.  One lane per LDE point and part, one launch per part.
+__global__ __launch_bounds__(256) void k_quotient_g1_sched(QArgs A) {
+  const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= ((size_t)2 << A.log_n)) return;
+  schedule_part<G1L, false>(A, j, next_position(j, A.log_n), 198, 5);
+}
+
+template <int part>
+__global__ __launch_bounds__(256, 3) void k_quotient_g1_add(QArgs A) {
   const unsigned log_n = A.log_n;
   const size_t N = (size_t)1 << log_n, M2 = 2 * N;
   const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= M2) return;
-  const size_t jn = next_position(j, log_n);
   const u64* __restrict__ tl = A.tl;
   const u64* __restrict__ W0 = A.W;
   const u64* __restrict__ W1 = A.W + A.K;
   u64 tot0 = 0, tot1 = 0;
   int e = 0;
-
+  const int AUX = G1_COL_AUX;
   const u64 filter = TL(G1_COL_FILTER);
-  // ---- eval_g1_add (add.rs:125-185) -----------------------------------------------------------------------
-  {
-    const int AUX = G1_COL_AUX;
-    u64 ax[16], bx[16], dx[16], lam[16], t16[16];
-    ld16(tl, M2, j, G1_COL_A, ax);
-    ld16(tl, M2, j, G1_COL_B, bx);
-#pragma unroll
-    for (int i = 0; i < 16; i++) dx[i] = gl_sub(bx[i], ax[i]);
-    ld16(tl, M2, j, AUX + G1_AUX_LAMBDA, lam);
+  const u64 is_x_eq_filter = TL(AUX + G1_AUX_IS_X_EQ_FILTER);
+  u64 ax[16], lam[16], t16[16], u16[16];
+  ld16(tl, M2, j, G1_COL_A, ax);
+  if constexpr (part == 0) {
+    // block 0: delta_x * inv - 1 + is_x_eq (eval_is_modulus_zero), then filter*is_x_eq*delta_x[i], then e = 49
     const u64 is_x_eq = TL(AUX + G1_AUX_IS_X_EQ);
-    const u64 is_x_eq_filter = TL(AUX + G1_AUX_IS_X_EQ_FILTER);
-    // block 0: delta_x * inv - 1 + is_x_eq   (eval_is_modulus_zero)
-    {
-      ld16(tl, M2, j, AUX + G1_AUX_IS_X_EQ_AUX, t16);  // inv limbs
-      const u64 c0 = gl_sub(is_x_eq, 1);
-      mz_block(tl, M2, j, AUX + G1_AUX_IS_X_EQ_AUX + 16, W0 + G1_MZ_E0[0], W1 + G1_MZ_E0[0], A.mzt + 0 * 160, A.mzt + 0 * 160 + 80,
-               filter, [&](int i) { u64 v = conv16(dx, t16, i); return i == 0 ? gl_add(v, c0) : v; }, tot0, tot1);
-      e = 33;
-      // filter * (delta_x[i] * is_x_eq)
-      Acc2 g;
-      acc2_init(g);
+    ld16(tl, M2, j, G1_COL_B, u16);
 #pragma unroll
-      for (int i = 0; i < 16; i++) acc2_mad(g, dx[i], W0[e + i], W1[e + i]);
-      e += 16;
-      u64 f = gl_mul(filter, is_x_eq);
-      tot0 = gl_add(tot0, gl_mul(f, acc_red(g.a0)));
-      tot1 = gl_add(tot1, gl_mul(f, acc_red(g.a1)));
-    }
+    for (int i = 0; i < 16; i++) u16[i] = gl_sub(u16[i], ax[i]);  // delta_x
+    ld16(tl, M2, j, AUX + G1_AUX_IS_X_EQ_AUX, t16);               // inv limbs
+    const u64 c0 = gl_sub(is_x_eq, 1);
+    mz_block(tl, M2, j, AUX + G1_AUX_IS_X_EQ_AUX + 16, W0 + G1_MZ_E0[0], W1 + G1_MZ_E0[0], A.mzt + 0 * 160, A.mzt + 0 * 160 + 80,
+             filter, [&](int i) { u64 v = conv16(u16, t16, i); return i == 0 ? gl_add(v, c0) : v; }, tot0, tot1);
+    e = 33;
+    Acc2 g;
+    acc2_init(g);
+#pragma unroll
+    for (int i = 0; i < 16; i++) acc2_mad(g, u16[i], W0[e + i], W1[e + i]);
+    e += 16;
+    u64 f = gl_mul(filter, is_x_eq);
+    tot0 = gl_add(tot0, gl_mul(f, acc_red(g.a0)));
+    tot1 = gl_add(tot1, gl_mul(f, acc_red(g.a1)));
     EMIT(gl_sub(gl_mul(filter, is_x_eq), is_x_eq_filter));  // e = 49
-    const u64 is_not_eq_filter = gl_sub(filter, is_x_eq_filter);
-    u64 ay[16];
-    ld16(tl, M2, j, G1_COL_A + 16, ay);
-    // block 1: lambda*delta_x - (b.y - a.y)
-    {
-      ld16(tl, M2, j, G1_COL_B + 16, t16);  // b.y
-      mz_block(tl, M2, j, AUX + G1_AUX_LAMBDA_AUX, W0 + G1_MZ_E0[1], W1 + G1_MZ_E0[1], A.mzt + 1 * 160, A.mzt + 1 * 160 + 80,
-               is_not_eq_filter,
-               [&](int i) {
-                 u64 v = conv16(lam, dx, i);
-                 return i < 16 ? gl_sub(v, gl_sub(t16[i < 16 ? i : 0], ay[i < 16 ? i : 0])) : v;
-               },
-               tot0, tot1);
-    }
-    // block 2: 2*lambda*a.y - 3*a.x^2
+  } else if constexpr (part == 1) {
+    // block 1: lambda*delta_x - (b.y - a.y) under filter - is_x_eq_filter
+    ld16(tl, M2, j, AUX + G1_AUX_LAMBDA, lam);
+    ld16(tl, M2, j, G1_COL_B, u16);
+#pragma unroll
+    for (int i = 0; i < 16; i++) u16[i] = gl_sub(u16[i], ax[i]);  // delta_x
+    ld16(tl, M2, j, G1_COL_B + 16, t16);                          // b.y
+    ld16(tl, M2, j, G1_COL_A + 16, ax);                           // a.y (a.x no longer needed)
+    mz_block(tl, M2, j, AUX + G1_AUX_LAMBDA_AUX, W0 + G1_MZ_E0[1], W1 + G1_MZ_E0[1], A.mzt + 1 * 160, A.mzt + 1 * 160 + 80,
+             gl_sub(filter, is_x_eq_filter),
+             [&](int i) {
+               u64 v = conv16(lam, u16, i);
+               return i < 16 ? gl_sub(v, gl_sub(t16[i < 16 ? i : 0], ax[i < 16 ? i : 0])) : v;
+             },
+             tot0, tot1);
+  } else if constexpr (part == 2) {
+    // block 2: 2*lambda*a.y - 3*a.x^2 under is_x_eq_filter, then a.y == b.y (e = 116..131)
+    ld16(tl, M2, j, AUX + G1_AUX_LAMBDA, lam);
+    ld16(tl, M2, j, G1_COL_A + 16, u16);  // a.y
     mz_block(tl, M2, j, AUX + G1_AUX_LAMBDA_AUX, W0 + G1_MZ_E0[2], W1 + G1_MZ_E0[2], A.mzt + 2 * 160, A.mzt + 2 * 160 + 80,
              is_x_eq_filter,
              [&](int i) {
-               u64 ly = conv16(lam, ay, i), xx = conv16(ax, ax, i);
+               u64 ly = conv16(lam, u16, i), xx = conv16(ax, ax, i);
                return gl_sub(gl_dbl(ly), gl_add(gl_dbl(xx), xx));
              },
              tot0, tot1);
     e = 116;
-    // a.y == b.y under is_x_eq_filter
-    {
-      ld16(tl, M2, j, G1_COL_B + 16, t16);
-      Acc2 g;
-      acc2_init(g);
+    ld16(tl, M2, j, G1_COL_B + 16, t16);
+    Acc2 g;
+    acc2_init(g);
 #pragma unroll
-      for (int i = 0; i < 16; i++) acc2_mad(g, gl_sub(ay[i], t16[i]), W0[e + i], W1[e + i]);
-      e += 16;
-      tot0 = gl_add(tot0, gl_mul(is_x_eq_filter, acc_red(g.a0)));
-      tot1 = gl_add(tot1, gl_mul(is_x_eq_filter, acc_red(g.a1)));
-    }
+    for (int i = 0; i < 16; i++) acc2_mad(g, gl_sub(u16[i], t16[i]), W0[e + i], W1[e + i]);
+    tot0 = gl_add(tot0, gl_mul(is_x_eq_filter, acc_red(g.a0)));
+    tot1 = gl_add(tot1, gl_mul(is_x_eq_filter, acc_red(g.a1)));
+  } else if constexpr (part == 3) {
     // block 3: lambda^2 - (a.x + b.x + c.x)
-    u64 cx[16];
-    ld16(tl, M2, j, G1_COL_C, cx);
+    ld16(tl, M2, j, AUX + G1_AUX_LAMBDA, lam);
+    ld16(tl, M2, j, G1_COL_B, t16);
+    ld16(tl, M2, j, G1_COL_C, u16);
     mz_block(tl, M2, j, AUX + G1_AUX_X_AUX, W0 + G1_MZ_E0[3], W1 + G1_MZ_E0[3], A.mzt + 3 * 160, A.mzt + 3 * 160 + 80, filter,
              [&](int i) {
                u64 v = conv16(lam, lam, i);
-               return i < 16 ? gl_sub(v, gl_add(gl_add(ax[i < 16 ? i : 0], bx[i < 16 ? i : 0]), cx[i < 16 ? i : 0])) : v;
+               return i < 16 ? gl_sub(v, gl_add(gl_add(ax[i < 16 ? i : 0], t16[i < 16 ? i : 0]), u16[i < 16 ? i : 0])) : v;
              },
              tot0, tot1);
+  } else {
     // block 4: lambda*(c.x - a.x) + c.y + a.y
-    {
+    ld16(tl, M2, j, AUX + G1_AUX_LAMBDA, lam);
+    ld16(tl, M2, j, G1_COL_C, u16);
 #pragma unroll
-      for (int i = 0; i < 16; i++) dx[i] = gl_sub(cx[i], ax[i]);  // reuse dx as c.x - a.x
-      ld16(tl, M2, j, G1_COL_C + 16, t16);                          // c.y
-      mz_block(tl, M2, j, AUX + G1_AUX_Y_AUX, W0 + G1_MZ_E0[4], W1 + G1_MZ_E0[4], A.mzt + 4 * 160, A.mzt + 4 * 160 + 80, filter,
-               [&](int i) {
-                 u64 v = conv16(lam, dx, i);
-                 return i < 16 ? gl_add(v, gl_add(t16[i < 16 ? i : 0], ay[i < 16 ? i : 0])) : v;
-               },
-               tot0, tot1);
-    }
-    e = 198;
+    for (int i = 0; i < 16; i++) u16[i] = gl_sub(u16[i], ax[i]);  // c.x - a.x
+    ld16(tl, M2, j, G1_COL_C + 16, t16);                          // c.y
+    ld16(tl, M2, j, G1_COL_A + 16, ax);                           // a.y
+    mz_block(tl, M2, j, AUX + G1_AUX_Y_AUX, W0 + G1_MZ_E0[4], W1 + G1_MZ_E0[4], A.mzt + 4 * 160, A.mzt + 4 * 160 + 80, filter,
+             [&](int i) {
+               u64 v = conv16(lam, u16, i);
+               return i < 16 ? gl_add(v, gl_add(t16[i < 16 ? i : 0], ax[i < 16 ? i : 0])) : v;
+             },
+             tot0, tot1);
   }
+  store_part(A, part, j, tot0, tot1);
+}
 
-  schedule_and_finish<G1L, false>(A, sh, j, jn, e, tot0, tot1);
+__global__ __launch_bounds__(256) void k_quotient_finish(QArgs A, StarkShape sh) {
+  const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= ((size_t)2 << A.log_n)) return;
+  finish_point(A, sh, j);
+}
+void quotient_finish_launch(const QArgs& A, const StarkShape& sh, hipStream_t st) {
+  size_t M2 = (size_t)2 << A.log_n;
+  k_quotient_finish<<<(unsigned)((M2 + 255) / 256), 256, 0, st>>>(A, sh);
 }
 
 // ---- per-context point tables ---------------------------------------------------------------------------------
@@ -182,7 +196,8 @@ void quotient_host_tables(int K, const u64 alphas[2], const int* mz_e0, int n_bl
 }
 
 void quotient_fill_args(QArgs& A, const StarkShape& sh, const u64* d_tl, const u64* d_al, const u64* d_W, const u64* d_mzt,
-                        const QPointTables& pt, const u64 betas[2], const u64 gammas[2], unsigned log_n, u64* d_out) {
+                        const QPointTables& pt, const u64 betas[2], const u64 gammas[2], unsigned log_n, u64* d_out,
+                        u64* d_part) {
   A.tl = d_tl;
   A.al = d_al;
   A.W = d_W;
@@ -198,6 +213,8 @@ void quotient_fill_args(QArgs& A, const StarkShape& sh, const u64* d_tl, const u
   A.zh_inv[1] = gl_inv(gl_sub(gl_neg(gn), 1));
   A.w_inv = gl_inv(gl_root_of_unity(log_n));
   A.out = d_out;
+  A.part = d_part;
+  A.n_parts = 0;
   A.log_n = log_n;
   A.K = sh.n_total_constraints();
 }
@@ -206,7 +223,16 @@ int g1_quotient_mz_blocks(const int** e0) {
   *e0 = G1_MZ_E0;
   return 5;
 }
-void g1_quotient_launch(const QArgs& A, const StarkShape& sh, hipStream_t st) {
+void g1_quotient_launch(const QArgs& A0, const StarkShape& sh, hipStream_t st) {
+  QArgs A = A0;
+  A.n_parts = 6;
   size_t M2 = (size_t)2 << A.log_n;
-  k_quotient_g1<<<(unsigned)((M2 + 255) / 256), 256, 0, st>>>(A, sh);
+  const unsigned g = (unsigned)((M2 + 255) / 256);
+  k_quotient_g1_add<0><<<g, 256, 0, st>>>(A);
+  k_quotient_g1_add<1><<<g, 256, 0, st>>>(A);
+  k_quotient_g1_add<2><<<g, 256, 0, st>>>(A);
+  k_quotient_g1_add<3><<<g, 256, 0, st>>>(A);
+  k_quotient_g1_add<4><<<g, 256, 0, st>>>(A);
+  k_quotient_g1_sched<<<g, 256, 0, st>>>(A);
+  quotient_finish_launch(A, sh, st);
 }

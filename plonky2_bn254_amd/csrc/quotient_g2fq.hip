@@ -23,13 +23,20 @@ __device__ __forceinline__ u64 econv_c1(const u64* x0, const u64* x1, const u64*
 #define MZB(blk, auxcol, FILTER, ...) \
   mz_block(tl, M2, j, (auxcol), W0 + G2_MZ_E0[blk], W1 + G2_MZ_E0[blk], A.mzt + (blk) * 160, A.mzt + (blk) * 160 + 80, (FILTER), __VA_ARGS__, tot0, tot1)
 
-__global__ __launch_bounds__(256) void k_quotient_g2(QArgs A, StarkShape sh) {
+__global__ __launch_bounds__(256) void k_quotient_g2_sched(QArgs A) {
+  const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= ((size_t)2 << A.log_n)) return;
+  schedule_part<G2L, false>(A, j, next_position(j, A.log_n), 396, 5);
+}
+
+// Parts 0..4 of eval_g2_add: {is-zero witnesses of delta_x, lambda (x !=), lambda (x ==) + a.y == b.y, x, y}.
+template <int part>
+__global__ __launch_bounds__(256, 2) void k_quotient_g2_add(QArgs A) {
   typedef G2L L;
   const unsigned log_n = A.log_n;
   const size_t N = (size_t)1 << log_n, M2 = 2 * N;
   const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= M2) return;
-  const size_t jn = next_position(j, log_n);
   const u64* __restrict__ tl = A.tl;
   const u64* __restrict__ W0 = A.W;
   const u64* __restrict__ W1 = A.W + A.K;
@@ -37,127 +44,147 @@ __global__ __launch_bounds__(256) void k_quotient_g2(QArgs A, StarkShape sh) {
   int e = 0;
   const u64 filter = TL(L::FILTER);
   const int AUX = L::AUX;
-  const u64 is_x_eq = TL(AUX + G2_AUX_IS_X_EQ), z0 = TL(AUX + G2_AUX_IS_C0_ZERO), z1 = TL(AUX + G2_AUX_IS_C1_ZERO);
   const u64 is_x_eq_filter = TL(AUX + G2_AUX_IS_X_EQ_FILTER);
-  // eval_is_ext_modulus_zero
-  EMIT(gl_mul(filter, gl_sub(gl_mul(z0, z1), is_x_eq)));  // e = 0
   u64 ax0[16], ax1[16], dx0[16], dx1[16], t0[16], t1[16];
   ld16(tl, M2, j, L::A, ax0);
   ld16(tl, M2, j, L::A + 16, ax1);
-  ld16(tl, M2, j, L::B, t0);
-  ld16(tl, M2, j, L::B + 16, t1);
+  if constexpr (part == 0) {
+    const u64 is_x_eq = TL(AUX + G2_AUX_IS_X_EQ), z0 = TL(AUX + G2_AUX_IS_C0_ZERO), z1 = TL(AUX + G2_AUX_IS_C1_ZERO);
+    EMIT(gl_mul(filter, gl_sub(gl_mul(z0, z1), is_x_eq)));  // e = 0
+    ld16(tl, M2, j, L::B, dx0);
+    ld16(tl, M2, j, L::B + 16, dx1);
 #pragma unroll
-  for (int i = 0; i < 16; i++) {
-    dx0[i] = gl_sub(t0[i], ax0[i]);
-    dx1[i] = gl_sub(t1[i], ax1[i]);
+    for (int i = 0; i < 16; i++) {
+      dx0[i] = gl_sub(dx0[i], ax0[i]);
+      dx1[i] = gl_sub(dx1[i], ax1[i]);
+    }
+    {
+      ld16(tl, M2, j, AUX + G2_AUX_C0_AUX, t0);  // inv of delta_x.c0
+      const u64 c0 = gl_sub(z0, 1);
+      MZB(0, AUX + G2_AUX_C0_AUX + 16, filter, [&](int i) { u64 v = conv16(dx0, t0, i); return i == 0 ? gl_add(v, c0) : v; });
+      e = 34;
+      Acc2 g;
+      acc2_init(g);
+#pragma unroll
+      for (int i = 0; i < 16; i++) acc2_mad(g, dx0[i], W0[e + i], W1[e + i]);
+      u64 f = gl_mul(filter, z0);
+      tot0 = gl_add(tot0, gl_mul(f, acc_red(g.a0)));
+      tot1 = gl_add(tot1, gl_mul(f, acc_red(g.a1)));
+    }
+    {
+      ld16(tl, M2, j, AUX + G2_AUX_C1_AUX, t0);  // inv of delta_x.c1
+      const u64 c0 = gl_sub(z1, 1);
+      MZB(1, AUX + G2_AUX_C1_AUX + 16, filter, [&](int i) { u64 v = conv16(dx1, t0, i); return i == 0 ? gl_add(v, c0) : v; });
+      e = 83;
+      Acc2 g;
+      acc2_init(g);
+#pragma unroll
+      for (int i = 0; i < 16; i++) acc2_mad(g, dx1[i], W0[e + i], W1[e + i]);
+      u64 f = gl_mul(filter, z1);
+      tot0 = gl_add(tot0, gl_mul(f, acc_red(g.a0)));
+      tot1 = gl_add(tot1, gl_mul(f, acc_red(g.a1)));
+    }
+    e = 99;
+    EMIT(gl_sub(gl_mul(filter, is_x_eq), is_x_eq_filter));
+  } else {
+    u64 l0[16], l1[16];
+    ld16(tl, M2, j, AUX + G2_AUX_LAMBDA, l0);
+    ld16(tl, M2, j, AUX + G2_AUX_LAMBDA + 16, l1);
+    if constexpr (part == 1) {
+      // lambda * delta_x - (b.y - a.y) under filter - is_x_eq_filter
+      ld16(tl, M2, j, L::B, dx0);
+      ld16(tl, M2, j, L::B + 16, dx1);
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+        dx0[i] = gl_sub(dx0[i], ax0[i]);
+        dx1[i] = gl_sub(dx1[i], ax1[i]);
+      }
+      ld16(tl, M2, j, L::B + 32, t0);
+      ld16(tl, M2, j, L::B + 48, t1);
+      ld16(tl, M2, j, L::A + 32, ax0);  // a.y (a.x no longer needed)
+      ld16(tl, M2, j, L::A + 48, ax1);
+      const u64 f_ne = gl_sub(filter, is_x_eq_filter);
+      MZB(2, AUX + G2_AUX_LAMBDA_AUX, f_ne, [&](int i) {
+        u64 v = econv_c0(l0, l1, dx0, dx1, i);
+        return i < 16 ? gl_sub(v, gl_sub(t0[i < 16 ? i : 0], ax0[i < 16 ? i : 0])) : v;
+      });
+      MZB(3, AUX + G2_AUX_LAMBDA_AUX + 80, f_ne, [&](int i) {
+        u64 v = econv_c1(l0, l1, dx0, dx1, i);
+        return i < 16 ? gl_sub(v, gl_sub(t1[i < 16 ? i : 0], ax1[i < 16 ? i : 0])) : v;
+      });
+    } else if constexpr (part == 2) {
+      // 2 * lambda * a.y - 3 * a.x^2 under is_x_eq_filter, then a.y == b.y
+      ld16(tl, M2, j, L::A + 32, dx0);  // a.y
+      ld16(tl, M2, j, L::A + 48, dx1);
+      MZB(4, AUX + G2_AUX_LAMBDA_AUX, is_x_eq_filter, [&](int i) {
+        u64 ly = econv_c0(l0, l1, dx0, dx1, i), xx = econv_c0(ax0, ax1, ax0, ax1, i);
+        return gl_sub(gl_dbl(ly), gl_add(gl_dbl(xx), xx));
+      });
+      MZB(5, AUX + G2_AUX_LAMBDA_AUX + 80, is_x_eq_filter, [&](int i) {
+        u64 ly = econv_c1(l0, l1, dx0, dx1, i), xx = econv_c1(ax0, ax1, ax0, ax1, i);
+        return gl_sub(gl_dbl(ly), gl_add(gl_dbl(xx), xx));
+      });
+      e = 232;
+      ld16(tl, M2, j, L::B + 32, t0);
+      ld16(tl, M2, j, L::B + 48, t1);
+      Acc2 g;
+      acc2_init(g);
+#pragma unroll
+      for (int i = 0; i < 16; i++) acc2_mad(g, gl_sub(dx0[i], t0[i]), W0[e + i], W1[e + i]);
+#pragma unroll
+      for (int i = 0; i < 16; i++) acc2_mad(g, gl_sub(dx1[i], t1[i]), W0[e + 16 + i], W1[e + 16 + i]);
+      tot0 = gl_add(tot0, gl_mul(is_x_eq_filter, acc_red(g.a0)));
+      tot1 = gl_add(tot1, gl_mul(is_x_eq_filter, acc_red(g.a1)));
+    } else if constexpr (part == 3) {
+      // lambda^2 - (a.x + b.x + c.x)
+      ld16(tl, M2, j, L::B, dx0);
+      ld16(tl, M2, j, L::B + 16, dx1);
+      ld16(tl, M2, j, L::C, t0);
+      ld16(tl, M2, j, L::C + 16, t1);
+      MZB(6, AUX + G2_AUX_X_AUX, filter, [&](int i) {
+        u64 v = econv_c0(l0, l1, l0, l1, i);
+        return i < 16 ? gl_sub(v, gl_add(gl_add(ax0[i < 16 ? i : 0], dx0[i < 16 ? i : 0]), t0[i < 16 ? i : 0])) : v;
+      });
+      MZB(7, AUX + G2_AUX_X_AUX + 80, filter, [&](int i) {
+        u64 v = econv_c1(l0, l1, l0, l1, i);
+        return i < 16 ? gl_sub(v, gl_add(gl_add(ax1[i < 16 ? i : 0], dx1[i < 16 ? i : 0]), t1[i < 16 ? i : 0])) : v;
+      });
+    } else {
+      // lambda * (c.x - a.x) + c.y + a.y
+      ld16(tl, M2, j, L::C, dx0);
+      ld16(tl, M2, j, L::C + 16, dx1);
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+        dx0[i] = gl_sub(dx0[i], ax0[i]);
+        dx1[i] = gl_sub(dx1[i], ax1[i]);
+      }
+      ld16(tl, M2, j, L::C + 32, t0);
+      ld16(tl, M2, j, L::C + 48, t1);
+      ld16(tl, M2, j, L::A + 32, ax0);  // a.y
+      ld16(tl, M2, j, L::A + 48, ax1);
+      MZB(8, AUX + G2_AUX_Y_AUX, filter, [&](int i) {
+        u64 v = econv_c0(l0, l1, dx0, dx1, i);
+        return i < 16 ? gl_add(v, gl_add(t0[i < 16 ? i : 0], ax0[i < 16 ? i : 0])) : v;
+      });
+      MZB(9, AUX + G2_AUX_Y_AUX + 80, filter, [&](int i) {
+        u64 v = econv_c1(l0, l1, dx0, dx1, i);
+        return i < 16 ? gl_add(v, gl_add(t1[i < 16 ? i : 0], ax1[i < 16 ? i : 0])) : v;
+      });
+    }
   }
-  {
-    ld16(tl, M2, j, AUX + G2_AUX_C0_AUX, t0);  // inv of delta_x.c0
-    const u64 c0 = gl_sub(z0, 1);
-    MZB(0, AUX + G2_AUX_C0_AUX + 16, filter, [&](int i) { u64 v = conv16(dx0, t0, i); return i == 0 ? gl_add(v, c0) : v; });
-    e = 34;
-    Acc2 g;
-    acc2_init(g);
-#pragma unroll
-    for (int i = 0; i < 16; i++) acc2_mad(g, dx0[i], W0[e + i], W1[e + i]);
-    e += 16;
-    u64 f = gl_mul(filter, z0);
-    tot0 = gl_add(tot0, gl_mul(f, acc_red(g.a0)));
-    tot1 = gl_add(tot1, gl_mul(f, acc_red(g.a1)));
-  }
-  {
-    ld16(tl, M2, j, AUX + G2_AUX_C1_AUX, t0);  // inv of delta_x.c1
-    const u64 c0 = gl_sub(z1, 1);
-    MZB(1, AUX + G2_AUX_C1_AUX + 16, filter, [&](int i) { u64 v = conv16(dx1, t0, i); return i == 0 ? gl_add(v, c0) : v; });
-    e = 83;
-    Acc2 g;
-    acc2_init(g);
-#pragma unroll
-    for (int i = 0; i < 16; i++) acc2_mad(g, dx1[i], W0[e + i], W1[e + i]);
-    e += 16;
-    u64 f = gl_mul(filter, z1);
-    tot0 = gl_add(tot0, gl_mul(f, acc_red(g.a0)));
-    tot1 = gl_add(tot1, gl_mul(f, acc_red(g.a1)));
-  }
-  EMIT(gl_sub(gl_mul(filter, is_x_eq), is_x_eq_filter));  // e = 99
-  const u64 is_not_eq_filter = gl_sub(filter, is_x_eq_filter);
-  u64 l0[16], l1[16], ay0[16], ay1[16];
-  ld16(tl, M2, j, AUX + G2_AUX_LAMBDA, l0);
-  ld16(tl, M2, j, AUX + G2_AUX_LAMBDA + 16, l1);
-  ld16(tl, M2, j, L::A + 32, ay0);
-  ld16(tl, M2, j, L::A + 48, ay1);
-  // lambda * delta_x - (b.y - a.y)
-  ld16(tl, M2, j, L::B + 32, t0);
-  ld16(tl, M2, j, L::B + 48, t1);
-  MZB(2, AUX + G2_AUX_LAMBDA_AUX, is_not_eq_filter, [&](int i) {
-    u64 v = econv_c0(l0, l1, dx0, dx1, i);
-    return i < 16 ? gl_sub(v, gl_sub(t0[i < 16 ? i : 0], ay0[i < 16 ? i : 0])) : v;
-  });
-  MZB(3, AUX + G2_AUX_LAMBDA_AUX + 80, is_not_eq_filter, [&](int i) {
-    u64 v = econv_c1(l0, l1, dx0, dx1, i);
-    return i < 16 ? gl_sub(v, gl_sub(t1[i < 16 ? i : 0], ay1[i < 16 ? i : 0])) : v;
-  });
-  // 2 * lambda * a.y - 3 * a.x^2
-  MZB(4, AUX + G2_AUX_LAMBDA_AUX, is_x_eq_filter, [&](int i) {
-    u64 ly = econv_c0(l0, l1, ay0, ay1, i), xx = econv_c0(ax0, ax1, ax0, ax1, i);
-    return gl_sub(gl_dbl(ly), gl_add(gl_dbl(xx), xx));
-  });
-  MZB(5, AUX + G2_AUX_LAMBDA_AUX + 80, is_x_eq_filter, [&](int i) {
-    u64 ly = econv_c1(l0, l1, ay0, ay1, i), xx = econv_c1(ax0, ax1, ax0, ax1, i);
-    return gl_sub(gl_dbl(ly), gl_add(gl_dbl(xx), xx));
-  });
-  e = 232;
-  {  // a.y == b.y under is_x_eq_filter (c0 limbs then c1 limbs)
-    Acc2 g;
-    acc2_init(g);
-#pragma unroll
-    for (int i = 0; i < 16; i++) acc2_mad(g, gl_sub(ay0[i], t0[i]), W0[e + i], W1[e + i]);
-#pragma unroll
-    for (int i = 0; i < 16; i++) acc2_mad(g, gl_sub(ay1[i], t1[i]), W0[e + 16 + i], W1[e + 16 + i]);
-    e += 32;
-    tot0 = gl_add(tot0, gl_mul(is_x_eq_filter, acc_red(g.a0)));
-    tot1 = gl_add(tot1, gl_mul(is_x_eq_filter, acc_red(g.a1)));
-  }
-  // lambda^2 - (a.x + b.x + c.x)
-  u64 cx0[16], cx1[16];
-  ld16(tl, M2, j, L::C, cx0);
-  ld16(tl, M2, j, L::C + 16, cx1);
-  MZB(6, AUX + G2_AUX_X_AUX, filter, [&](int i) {
-    u64 v = econv_c0(l0, l1, l0, l1, i);
-    // b.x = delta_x + a.x
-    return i < 16 ? gl_sub(v, gl_add(gl_add(gl_dbl(ax0[i < 16 ? i : 0]), dx0[i < 16 ? i : 0]), cx0[i < 16 ? i : 0])) : v;
-  });
-  MZB(7, AUX + G2_AUX_X_AUX + 80, filter, [&](int i) {
-    u64 v = econv_c1(l0, l1, l0, l1, i);
-    return i < 16 ? gl_sub(v, gl_add(gl_add(gl_dbl(ax1[i < 16 ? i : 0]), dx1[i < 16 ? i : 0]), cx1[i < 16 ? i : 0])) : v;
-  });
-  // lambda * (c.x - a.x) + c.y + a.y
-#pragma unroll
-  for (int i = 0; i < 16; i++) {
-    dx0[i] = gl_sub(cx0[i], ax0[i]);
-    dx1[i] = gl_sub(cx1[i], ax1[i]);
-  }
-  ld16(tl, M2, j, L::C + 32, t0);
-  ld16(tl, M2, j, L::C + 48, t1);
-  MZB(8, AUX + G2_AUX_Y_AUX, filter, [&](int i) {
-    u64 v = econv_c0(l0, l1, dx0, dx1, i);
-    return i < 16 ? gl_add(v, gl_add(t0[i < 16 ? i : 0], ay0[i < 16 ? i : 0])) : v;
-  });
-  MZB(9, AUX + G2_AUX_Y_AUX + 80, filter, [&](int i) {
-    u64 v = econv_c1(l0, l1, dx0, dx1, i);
-    return i < 16 ? gl_add(v, gl_add(t1[i < 16 ? i : 0], ay1[i < 16 ? i : 0])) : v;
-  });
-  e = 396;
-  schedule_and_finish<G2L, false>(A, sh, j, jn, e, tot0, tot1);
+  store_part(A, part, j, tot0, tot1);
 }
 
-__global__ __launch_bounds__(256) void k_quotient_fq(QArgs A, StarkShape sh) {
+__global__ __launch_bounds__(256) void k_quotient_fq_sched(QArgs A) {
+  const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= ((size_t)2 << A.log_n)) return;
+  schedule_part<FQL, true>(A, j, next_position(j, A.log_n), 33, 1);
+}
+__global__ __launch_bounds__(256) void k_quotient_fq_mul(QArgs A) {
   typedef FQL L;
-  const unsigned log_n = A.log_n;
-  const size_t N = (size_t)1 << log_n, M2 = 2 * N;
+  const size_t M2 = (size_t)2 << A.log_n;
   const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= M2) return;
-  const size_t jn = next_position(j, log_n);
   const u64* __restrict__ tl = A.tl;
   const u64* __restrict__ W0 = A.W;
   const u64* __restrict__ W1 = A.W + A.K;
@@ -174,7 +201,7 @@ __global__ __launch_bounds__(256) void k_quotient_fq(QArgs A, StarkShape sh) {
              return i < 16 ? gl_sub(v, c[i < 16 ? i : 0]) : v;
            },
            tot0, tot1);
-  schedule_and_finish<FQL, true>(A, sh, j, jn, 33, tot0, tot1);
+  store_part(A, 0, j, tot0, tot1);
 }
 
 int g2_quotient_mz_blocks(const int** e0) {
@@ -185,11 +212,23 @@ int fq_quotient_mz_blocks(const int** e0) {
   *e0 = FQ_MZ_E0;
   return 1;
 }
-void g2_quotient_launch(const QArgs& A, const StarkShape& sh, hipStream_t st) {
-  size_t M2 = (size_t)2 << A.log_n;
-  k_quotient_g2<<<(unsigned)((M2 + 255) / 256), 256, 0, st>>>(A, sh);
+void g2_quotient_launch(const QArgs& A0, const StarkShape& sh, hipStream_t st) {
+  QArgs A = A0;
+  A.n_parts = 6;
+  const unsigned g = (unsigned)((((size_t)2 << A.log_n) + 255) / 256);
+  k_quotient_g2_add<0><<<g, 256, 0, st>>>(A);
+  k_quotient_g2_add<1><<<g, 256, 0, st>>>(A);
+  k_quotient_g2_add<2><<<g, 256, 0, st>>>(A);
+  k_quotient_g2_add<3><<<g, 256, 0, st>>>(A);
+  k_quotient_g2_add<4><<<g, 256, 0, st>>>(A);
+  k_quotient_g2_sched<<<g, 256, 0, st>>>(A);
+  quotient_finish_launch(A, sh, st);
 }
-void fq_quotient_launch(const QArgs& A, const StarkShape& sh, hipStream_t st) {
-  size_t M2 = (size_t)2 << A.log_n;
-  k_quotient_fq<<<(unsigned)((M2 + 255) / 256), 256, 0, st>>>(A, sh);
+void fq_quotient_launch(const QArgs& A0, const StarkShape& sh, hipStream_t st) {
+  QArgs A = A0;
+  A.n_parts = 2;
+  const unsigned g = (unsigned)((((size_t)2 << A.log_n) + 255) / 256);
+  k_quotient_fq_mul<<<g, 256, 0, st>>>(A);
+  k_quotient_fq_sched<<<g, 256, 0, st>>>(A);
+  quotient_finish_launch(A, sh, st);
 }

@@ -23,6 +23,8 @@ struct QArgs {
   u64 zh_inv[2];   // 1/Z_H on coset h
   u64 w_inv;       // w_N^-1 (last element of the subgroup)
   u64* out;        // [2 alphas][2 cosets][N] natural order
+  u64* part;       // partial sums [n_parts][2 alphas][2N], bit-reversed order
+  int n_parts;
   unsigned log_n;
   int K;
 };
@@ -58,9 +60,9 @@ __device__ __forceinline__ void mz_block(const u64* __restrict__ tl, size_t M2, 
   const u64 iqp = TL(auxcol + QMZ_IQP);
   acc2_mad(pos, gl_sub(gl_mul(iqp, iqp), iqp), w0[0], w1[0]);
   const u64 qsign = gl_sub(gl_dbl(iqp), 1);
-#pragma unroll
+#pragma unroll 1
   for (int jj = 0; jj < 17; jj++) acc2_mad(q, TL(auxcol + QMZ_QUOT + jj), T0[jj], T1[jj]);
-#pragma unroll
+#pragma unroll 1
   for (int d = 0; d < 31; d++) {
     acc2_mad(pos, TL(auxcol + QMZ_LO + d), T0[17 + d], T1[17 + d]);
     acc2_mad(pos, TL(auxcol + QMZ_HI + d), T0[48 + d], T1[48 + d]);
@@ -97,13 +99,20 @@ __device__ __forceinline__ void mz_block(const u64* __restrict__ tl, size_t M2, 
   }
 
 
-// Schedule constraints starting at constraint index e (e is advanced), then lookups + CTLs, then the division by
-// Z_H and the store.  L = LayoutT<..>.
+// The constraint stream is split over several kernels (add / mul blocks, schedule, lookups+CTLs): every part
+// writes its alpha-weighted partial sums, k_quotient_finish adds them.  Since acc_j = sum_e c_e alpha_j^(K-1-e) is
+// linear in the constraints, the split changes nothing but register pressure and the number of waves in flight.
+__device__ __forceinline__ void store_part(const QArgs& A, int part, size_t j, u64 tot0, u64 tot1) {
+  const size_t M2 = (size_t)2 << A.log_n;
+  A.part[((size_t)part * 2 + 0) * M2 + j] = tot0;
+  A.part[((size_t)part * 2 + 1) * M2 + j] = tot1;
+}
+
+// Schedule constraints starting at constraint index e; writes partial `part`.  L = LayoutT<..>.
 template <class L, bool FIRST_A_IS_ONE>
-__device__ __forceinline__ void schedule_and_finish(const QArgs& A, const StarkShape& sh, size_t j, size_t jn, int e, u64 tot0,
-                                                    u64 tot1) {
-  const unsigned log_n = A.log_n;
-  const size_t N = (size_t)1 << log_n, M2 = 2 * N;
+__device__ __forceinline__ void schedule_part(const QArgs& A, size_t j, size_t jn, int e, int part) {
+  u64 tot0 = 0, tot1 = 0;
+  const size_t M2 = (size_t)2 << A.log_n;
   const u64* __restrict__ tl = A.tl;
   const u64* __restrict__ W0 = A.W;
   const u64* __restrict__ W1 = A.W + A.K;
@@ -158,17 +167,31 @@ __device__ __forceinline__ void schedule_and_finish(const QArgs& A, const StarkS
   }
   EMIT(gl_mul(is_not_last_round, gl_sub(TN(L::TIMESTAMP), TL(L::TIMESTAMP))));   // 1107
   EMIT(gl_mul(is_not_last_round, gl_sub(n_filter, filter)));                             // 1108
-  const u64 x = A.pt.x[j], lfirst = A.pt.lfirst[j], llast = A.pt.llast[j];
+  const u64 x = A.pt.x[j], llast = A.pt.llast[j];
   const u64 z_last = gl_sub(x, A.w_inv);
   {
     const u64 rc = TL(L::RANGE), diff = gl_sub(TN(L::RANGE), rc);
     EMIT(gl_mul(gl_sub(gl_mul(diff, diff), diff), z_last));                              // 1109 transition
     EMIT(gl_mul(gl_sub(rc, 65535), llast));                                              // 1110 last row
   }
-  // ---- lookups + CTLs --------------------------------------------------------------------------------------
-  lookup_and_ctl_constraints(sh, tl, A.al, M2, j, jn, W0, W1, e, A.betas, A.gammas, lfirst, llast, z_last, tot0, tot1);
+  store_part(A, part, j, tot0, tot1);
+}
 
-  // divide by Z_H and store in natural order of the coset
+// Lookups + CTL constraints (they start at constraint index sh.n_constraints), sum of all partials, division by Z_H
+// and the store in natural order of the coset.
+__device__ __forceinline__ void finish_point(const QArgs& A, const StarkShape& sh, size_t j) {
+  const unsigned log_n = A.log_n;
+  const size_t N = (size_t)1 << log_n, M2 = 2 * N;
+  const size_t jn = next_position(j, log_n);
+  u64 tot0 = 0, tot1 = 0;
+  for (int p = 0; p < A.n_parts; p++) {
+    tot0 = gl_add(tot0, A.part[((size_t)p * 2 + 0) * M2 + j]);
+    tot1 = gl_add(tot1, A.part[((size_t)p * 2 + 1) * M2 + j]);
+  }
+  const u64 x = A.pt.x[j], lfirst = A.pt.lfirst[j], llast = A.pt.llast[j];
+  const u64 z_last = gl_sub(x, A.w_inv);
+  lookup_and_ctl_constraints(sh, A.tl, A.al, M2, j, jn, A.W, A.W + A.K, sh.n_constraints, A.betas, A.gammas, lfirst, llast,
+                             z_last, tot0, tot1);
   const size_t h = j >> log_n;
   const u32 k = bitrev32((u32)(j & (N - 1)), log_n);
   A.out[(0 * 2 + h) * N + k] = gl_mul(tot0, A.zh_inv[h]);
@@ -179,4 +202,7 @@ __device__ __forceinline__ void schedule_and_finish(const QArgs& A, const StarkS
 // eval_modulus_zero blocks whose first constraint indices are mz_e0[0..n_blocks).
 void quotient_host_tables(int K, const u64 alphas[2], const int* mz_e0, int n_blocks, std::vector<u64>& W, std::vector<u64>& mzt);
 void quotient_fill_args(QArgs& A, const StarkShape& sh, const u64* d_tl, const u64* d_al, const u64* d_W, const u64* d_mzt,
-                        const QPointTables& pt, const u64 betas[2], const u64 gammas[2], unsigned log_n, u64* d_out);
+                        const QPointTables& pt, const u64 betas[2], const u64 gammas[2], unsigned log_n, u64* d_out,
+                        u64* d_part);
+static constexpr int QUOTIENT_MAX_PARTS = 6;
+void quotient_finish_launch(const QArgs& A, const StarkShape& sh, hipStream_t st);
