@@ -52,6 +52,10 @@ void bn254s_ctx_destroy(bn254s_ctx* c) {
     hipStreamDestroy(s->st);
     delete s;
   }
+  for (auto& kv : c->tall) {
+    ntt_tall_tables_free(kv.second);
+    delete kv.second;
+  }
   c->release();
   ntt_tables_free(&c->ntt);
   hipStreamDestroy(c->stream);

@@ -51,6 +51,7 @@ struct bn254s_ctx : BufPool {
   hipStream_t stream = nullptr;
   NttTables ntt;
   std::vector<Slot*> slots;
+  std::map<unsigned, NttTallTables*> tall;  // per log_n
   // GPU-saturating kernels (NTT, leaf hashing, quotient, ...) of different slots are serialised with this lock:
   // they cannot run faster side by side, and alone they give clean per-kernel timings.  Latency-bound
   // kernels (EC chain, upper Merkle levels, scans, PoW) run outside it and overlap freely.

@@ -16,16 +16,21 @@
 #include "poseidon_dev.h"
 
 // ---- openings -----------------------------------------------------------------------------------------------
-// One 256-thread block per polynomial (coefficients, natural order).  out[p] = {P(z0).c0, .c1, P(z1).c0, .c1, P(1)}
-__global__ __launch_bounds__(256) void k_openings(const u64* __restrict__ coeffs, size_t N, gl2 z0, gl2 z1, u64* __restrict__ out) {
+// Coefficient layout: coefficient k1 + R*k2 at position k1*M + k2 (R = N / 2^16 blocks of M = 2^16; R = 1 is the
+// plain natural order).  P(z) = sum_k1 z^k1 * sum_k2 c[k1][k2] (z^R)^k2: one 256-thread block per (polynomial, k1)
+// evaluates the inner sum at zeta^R and (g zeta)^R; the host combines the R partial values.
+// out[(p*R + k1)*5 ..] = {S0.c0, S0.c1, S1.c0, S1.c1, sum of the block's coefficients}
+__global__ __launch_bounds__(256) void k_openings(const u64* __restrict__ coeffs, size_t N, unsigned log_r, gl2 z0r, gl2 z1r,
+                                                  u64* __restrict__ out) {
   __shared__ u64 red[256 * 5];
   const int t = threadIdx.x;
-  const u64* c = coeffs + (size_t)blockIdx.x * N;
-  // P(z) = sum_t z^t * sum_q c[t + 256 q] (z^256)^q
-  const gl2 z0p = gl2_pow(z0, 256), z1p = gl2_pow(z1, 256);
+  const size_t M = N >> log_r;
+  const u64* c = coeffs + (size_t)blockIdx.x * N + (size_t)blockIdx.y * M;
+  // S(z) = sum_t z^t * sum_q c[t + 256 q] (z^256)^q
+  const gl2 z0p = gl2_pow(z0r, 256), z1p = gl2_pow(z1r, 256);
   gl2 a0 = gl2_make(0, 0), a1 = gl2_make(0, 0);
   u64 s = 0;
-  for (long q = (long)(N / 256) - 1; q >= 0; q--) {
+  for (long q = (long)(M / 256) - 1; q >= 0; q--) {
     u64 v = c[(size_t)t + 256 * (size_t)q];
     a0 = gl2_mul(a0, z0p);
     a0.c0 = gl_add(a0.c0, v);
@@ -33,8 +38,8 @@ __global__ __launch_bounds__(256) void k_openings(const u64* __restrict__ coeffs
     a1.c0 = gl_add(a1.c0, v);
     s = gl_add(s, v);
   }
-  a0 = gl2_mul(a0, gl2_pow(z0, (u64)t));
-  a1 = gl2_mul(a1, gl2_pow(z1, (u64)t));
+  a0 = gl2_mul(a0, gl2_pow(z0r, (u64)t));
+  a1 = gl2_mul(a1, gl2_pow(z1r, (u64)t));
   red[t] = a0.c0;
   red[256 + t] = a0.c1;
   red[512 + t] = a1.c0;
@@ -46,11 +51,12 @@ __global__ __launch_bounds__(256) void k_openings(const u64* __restrict__ coeffs
       for (int k = 0; k < 5; k++) red[k * 256 + t] = gl_add(red[k * 256 + t], red[k * 256 + t + off]);
     __syncthreads();
   }
-  if (t < 5) out[(size_t)blockIdx.x * 5 + t] = red[t * 256];
+  if (t < 5) out[((size_t)blockIdx.x * gridDim.y + blockIdx.y) * 5 + t] = red[t * 256];
 }
 
-void fri_openings(const u64* d_coeffs, size_t N, int npolys, gl2 zeta, gl2 zeta_next, u64* d_out, hipStream_t st) {
-  k_openings<<<npolys, 256, 0, st>>>(d_coeffs, N, zeta, zeta_next, d_out);
+void fri_openings(const u64* d_coeffs, size_t N, unsigned log_r, int npolys, gl2 zeta, gl2 zeta_next, u64* d_out, hipStream_t st) {
+  const u64 R = (u64)1 << log_r;
+  k_openings<<<dim3(npolys, (unsigned)R), 256, 0, st>>>(d_coeffs, N, log_r, gl2_pow(zeta, R), gl2_pow(zeta_next, R), d_out);
 }
 
 // ---- batched quotient on the LDE domain ---------------------------------------------------------------

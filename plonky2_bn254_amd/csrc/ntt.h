@@ -19,3 +19,21 @@ void ntt_inverse(const NttTables* T, const u64* values, u64* coeffs, u64* tmp, i
 void ntt_coset_inverse(const NttTables* T, int h, const u64* values, u64* coeffs, u64* tmp, int ncols, hipStream_t s);
 void ntt_lde(const NttTables* T, const u64* coeffs, u64* lde, u64* tmp, int ncols, hipStream_t s);
 void ntt_coset_forward_natural(const NttTables* T, int h, const u64* coeffs, u64* values, u64* tmp, int ncols, hipStream_t s);
+
+// ---- N = R * 2^16 (tall traces) ---------------------------------------------------------------------------------
+struct NttTallTables {
+  unsigned log_n = 0;
+  u64* wn_inv_pow = nullptr;              // w_N^-i2, i2 < 2^16
+  u64* wn_pow_br = nullptr;               // w_N^bitrev16(p)
+  u64* block_coset_pow[2] = {nullptr, nullptr};  // (shift_h^R)^i2
+  u64 shift[2] = {0, 0};                  // g, g*w_2N
+  u64 r_inv = 0;
+};
+int ntt_tall_tables_init(NttTallTables* T, unsigned log_n);
+void ntt_tall_tables_free(NttTallTables* T);
+// Coefficients live in the "transposed" layout: coefficient k1 + R*k2 at position k1*2^16 + k2.
+void ntt_inverse_tall(const NttTables* T, const NttTallTables* TT, const u64* values, u64* coeffs, u64* tmp, int ncols,
+                      hipStream_t s);
+void ntt_coset_inverse_tall(const NttTables* T, const NttTallTables* TT, int h, const u64* values, u64* coeffs, u64* tmp, int ncols,
+                            hipStream_t s);
+void ntt_lde_tall(const NttTables* T, const NttTallTables* TT, const u64* coeffs, u64* lde, u64* tmp, int ncols, hipStream_t s);

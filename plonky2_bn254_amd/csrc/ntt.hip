@@ -84,15 +84,22 @@ __device__ __forceinline__ void dft256_tile(u64* x, u64* lds, const u64* __restr
 
 // ---- pass 1 ---------------------------------------------------------------------------------------------------
 // grid = (16 tiles, ncols); block = 256.  in/out column strides in elements.
+// For traces taller than 2^16 rows a column of N = R*2^16 words is R consecutive blocks; blockIdx.y then counts
+// (column, block) pairs: column = y >> log_r, block = y & (R-1)  (log_r = 0: one block per column).
+__device__ __forceinline__ size_t col_offset(unsigned y, unsigned log_r, size_t stride) {
+  return (size_t)(y >> log_r) * stride + (size_t)(y & ((1u << log_r) - 1)) * NTT_N;
+}
+
 template <bool INV>
 __global__ __launch_bounds__(256) void k_ntt_pass1(const u64* __restrict__ in, size_t in_stride, u64* __restrict__ out,
                                                    size_t out_stride, const u64* __restrict__ pre,
-                                                   const u64* __restrict__ twmat, const u64* __restrict__ tw256) {
+                                                   const u64* __restrict__ twmat, const u64* __restrict__ tw256,
+                                                   unsigned log_r) {
   __shared__ u64 lds[LDS_TILE_WORDS];
   const int t = threadIdx.x;
   int d = t & 15, g = t >> 4;
   const int i2 = blockIdx.x * 16 + d;
-  const u64* col = in + (size_t)blockIdx.y * in_stride;
+  const u64* col = in + col_offset(blockIdx.y, log_r, in_stride);
   u64 x[16];
 #pragma unroll
   for (int m = 0; m < 16; m++) x[m] = col[(g + 16 * m) * 256 + i2];
@@ -101,7 +108,7 @@ __global__ __launch_bounds__(256) void k_ntt_pass1(const u64* __restrict__ in, s
     for (int m = 0; m < 16; m++) x[m] = gl_mul(x[m], pre[(g + 16 * m) * 256 + i2]);
   }
   dft256_tile<INV, 0>(x, lds, tw256, d, g);
-  u64* ocol = out + (size_t)blockIdx.y * out_stride;
+  u64* ocol = out + col_offset(blockIdx.y, log_r, out_stride);
   const int ka = g;
 #pragma unroll
   for (int kb = 0; kb < 16; kb++) {
@@ -119,21 +126,21 @@ __global__ __launch_bounds__(256) void k_ntt_pass1(const u64* __restrict__ in, s
 template <bool INV, bool OUT_BITREV>
 __global__ __launch_bounds__(256) void k_ntt_pass2(const u64* __restrict__ in, size_t in_stride, u64* __restrict__ out,
                                                    size_t out_stride, const u64* __restrict__ post, u64 post_scalar,
-                                                   const u64* __restrict__ tw256) {
+                                                   const u64* __restrict__ tw256, unsigned log_r) {
   __shared__ u64 lds[LDS_TILE_WORDS];
   const int t = threadIdx.x;
   int g = t & 15, d = t >> 4;
   // bit-reversed output: rows k1 = b + 16 d (their images br8(k1) are 16 consecutive output rows);
   // natural output: rows k1 = 16 b + d (consecutive, so that stores along d are contiguous)
   const int k1_load = OUT_BITREV ? blockIdx.x + 16 * d : blockIdx.x * 16 + d;
-  const u64* col = in + (size_t)blockIdx.y * in_stride;
+  const u64* col = in + col_offset(blockIdx.y, log_r, in_stride);
   u64 x[16];
 #pragma unroll
   for (int m = 0; m < 16; m++) x[m] = col[k1_load * 256 + g + 16 * m];
   dft256_tile<INV, OUT_BITREV ? 1 : 2>(x, lds, tw256, d, g);
   const int k1 = OUT_BITREV ? blockIdx.x + 16 * d : blockIdx.x * 16 + d;
   const int ka = g;
-  u64* ocol = out + (size_t)blockIdx.y * out_stride;
+  u64* ocol = out + col_offset(blockIdx.y, log_r, out_stride);
   if (OUT_BITREV) {
     // position = br8(k1)*256 + br8(k2), k2 = ka + 16*kb  ->  br4(ka)*16 + br4(kb): x[] is already in
     // br4(kb) order, so the thread owns 16 consecutive words.
@@ -229,26 +236,227 @@ void ntt_tables_free(NttTables* T) {
 // values[C][N] (natural) -> coefficients[C][N] (natural); in place allowed (uses tmp[C][N]).
 void ntt_inverse(const NttTables* T, const u64* values, u64* coeffs, u64* tmp, int ncols, hipStream_t s) {
   dim3 grid(16, ncols), block(256);
-  k_ntt_pass1<true><<<grid, block, 0, s>>>(values, NTT_N, tmp, NTT_N, nullptr, T->twmat_inv, T->tw256_inv);
-  k_ntt_pass2<true, false><<<grid, block, 0, s>>>(tmp, NTT_N, coeffs, NTT_N, nullptr, T->n_inv, T->tw256_inv);
+  k_ntt_pass1<true><<<grid, block, 0, s>>>(values, NTT_N, tmp, NTT_N, nullptr, T->twmat_inv, T->tw256_inv, 0);
+  k_ntt_pass2<true, false><<<grid, block, 0, s>>>(tmp, NTT_N, coeffs, NTT_N, nullptr, T->n_inv, T->tw256_inv, 0);
 }
 // coset iNTT of values given on coset `h` (natural order) -> coefficients (natural)
 void ntt_coset_inverse(const NttTables* T, int h, const u64* values, u64* coeffs, u64* tmp, int ncols, hipStream_t s) {
   dim3 grid(16, ncols), block(256);
-  k_ntt_pass1<true><<<grid, block, 0, s>>>(values, NTT_N, tmp, NTT_N, nullptr, T->twmat_inv, T->tw256_inv);
-  k_ntt_pass2<true, false><<<grid, block, 0, s>>>(tmp, NTT_N, coeffs, NTT_N, T->coset_inv_pow[h], 1, T->tw256_inv);
+  k_ntt_pass1<true><<<grid, block, 0, s>>>(values, NTT_N, tmp, NTT_N, nullptr, T->twmat_inv, T->tw256_inv, 0);
+  k_ntt_pass2<true, false><<<grid, block, 0, s>>>(tmp, NTT_N, coeffs, NTT_N, T->coset_inv_pow[h], 1, T->tw256_inv, 0);
 }
 // coefficients[C][N] -> lde[C][2N] in bit-reversed order (both cosets); tmp[C][N].
 void ntt_lde(const NttTables* T, const u64* coeffs, u64* lde, u64* tmp, int ncols, hipStream_t s) {
   dim3 grid(16, ncols), block(256);
   for (int h = 0; h < 2; h++) {
-    k_ntt_pass1<false><<<grid, block, 0, s>>>(coeffs, NTT_N, tmp, NTT_N, T->coset_pow[h], T->twmat_fwd, T->tw256_fwd);
-    k_ntt_pass2<false, true><<<grid, block, 0, s>>>(tmp, NTT_N, lde + (size_t)h * NTT_N, 2 * NTT_N, nullptr, 1, T->tw256_fwd);
+    k_ntt_pass1<false><<<grid, block, 0, s>>>(coeffs, NTT_N, tmp, NTT_N, T->coset_pow[h], T->twmat_fwd, T->tw256_fwd, 0);
+    k_ntt_pass2<false, true><<<grid, block, 0, s>>>(tmp, NTT_N, lde + (size_t)h * NTT_N, 2 * NTT_N, nullptr, 1, T->tw256_fwd, 0);
   }
 }
 // forward coset NTT on coset h, natural output (used for small FRI-side transforms and tests)
 void ntt_coset_forward_natural(const NttTables* T, int h, const u64* coeffs, u64* values, u64* tmp, int ncols, hipStream_t s) {
   dim3 grid(16, ncols), block(256);
-  k_ntt_pass1<false><<<grid, block, 0, s>>>(coeffs, NTT_N, tmp, NTT_N, T->coset_pow[h], T->twmat_fwd, T->tw256_fwd);
-  k_ntt_pass2<false, false><<<grid, block, 0, s>>>(tmp, NTT_N, values, NTT_N, nullptr, 1, T->tw256_fwd);
+  k_ntt_pass1<false><<<grid, block, 0, s>>>(coeffs, NTT_N, tmp, NTT_N, T->coset_pow[h], T->twmat_fwd, T->tw256_fwd, 0);
+  k_ntt_pass2<false, false><<<grid, block, 0, s>>>(tmp, NTT_N, values, NTT_N, nullptr, 1, T->tw256_fwd, 0);
+}
+
+
+// ---- traces taller than 2^16 rows: N = R * 2^16, R = 2^log_r <= 16 -----------------------------------------------
+// An N-point transform is an R-point DFT across the R blocks of a column (shift-only twiddles, one lane per
+// in-block position, all accesses contiguous across lanes) combined with the 2^16-point kernels above on each block.
+//   inverse (values natural -> coefficients):  outer DIF pass first, then the block iNTTs.  Coefficient k1 + R*k2 ends
+//   up at [block k1][k2] ("transposed" coefficient layout; every consumer below and in fri.hip knows it).
+//   forward coset LDE (transposed coefficients -> bit-reversed values): block NTTs first (coset (shift^R)), then the
+//   outer DIT pass with twiddle (shift * w_N^k2)^i1; output position bitrev(k2)*R + bitrev_r(k1) = p*R + register index.
+__device__ __forceinline__ u64 mul_2exp12(u64 x, int e) {  // x * 2^(12 e), e in [0,16); e is a compile-time constant after unrolling
+  switch (e) {
+    case 0: return x;
+    case 1: return gl_mul_2exp<12>(x);
+    case 2: return gl_mul_2exp<24>(x);
+    case 3: return gl_mul_2exp<36>(x);
+    case 4: return gl_mul_2exp<48>(x);
+    case 5: return gl_mul_2exp<60>(x);
+    case 6: return gl_mul_2exp<72>(x);
+    case 7: return gl_mul_2exp<84>(x);
+    case 8: return gl_mul_2exp<96>(x);
+    case 9: return gl_mul_2exp<108>(x);
+    case 10: return gl_mul_2exp<120>(x);
+    case 11: return gl_mul_2exp<132>(x);
+    case 12: return gl_mul_2exp<144>(x);
+    case 13: return gl_mul_2exp<156>(x);
+    case 14: return gl_mul_2exp<168>(x);
+    default: return gl_mul_2exp<180>(x);
+  }
+}
+// R-point DIF network, R = 2^LOGR <= 16; output X[k] lands in x[bitrev_LOGR(k)].  w_R = 2^(192/R).
+template <int LOGR, bool INV>
+__device__ __forceinline__ void dft_small(u64* x) {
+  constexpr int R = 1 << LOGR;
+#pragma unroll
+  for (int s = 0; s < LOGR; s++) {
+    const int span = R >> (s + 1);
+#pragma unroll
+    for (int g0 = 0; g0 < R; g0 += 2 * span) {
+#pragma unroll
+      for (int jj = 0; jj < span; jj++) {
+        u64 a = x[g0 + jj], b = x[g0 + jj + span];
+        x[g0 + jj] = gl_add(a, b);
+        int e = (jj << s) * (16 >> LOGR);  // twiddle w_R^(jj * 2^s) = 2^(12 e)
+        if (INV) e = (16 - e) & 15;
+        x[g0 + jj + span] = mul_2exp12(gl_sub(a, b), e);
+      }
+    }
+  }
+}
+__device__ __forceinline__ constexpr int brn(int v, int bits) {
+  int r = 0;
+  for (int i = 0; i < bits; i++) r |= ((v >> i) & 1) << (bits - 1 - i);
+  return r;
+}
+
+// values[col][i1][i2] -> y[col][k1][i2] = (1/R) * w_N^-(i2 k1) * sum_i1 x[i1][i2] w_R^-(i1 k1)
+template <int LOGR>
+__global__ __launch_bounds__(256) void k_ntt_outer_inv(const u64* __restrict__ in, u64* __restrict__ out, size_t N,
+                                                       const u64* __restrict__ wn_inv_pow /* w_N^-i2 */, u64 r_inv) {
+  constexpr int R = 1 << LOGR;
+  const size_t i2 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const u64* c = in + (size_t)blockIdx.y * N;
+  u64* o = out + (size_t)blockIdx.y * N;
+  u64 x[R];
+#pragma unroll
+  for (int i1 = 0; i1 < R; i1++) x[i1] = c[(size_t)i1 * NTT_N + i2];
+  dft_small<LOGR, true>(x);
+  const u64 w = wn_inv_pow[i2];
+  u64 f = r_inv;
+#pragma unroll
+  for (int k1 = 0; k1 < R; k1++) {
+    o[(size_t)k1 * NTT_N + i2] = gl_mul(x[brn(k1, LOGR)], f);
+    f = gl_mul(f, w);
+  }
+}
+
+// z[col][i1][p] (block NTT outputs, p = bitrev16(k2)) -> out[col*out_stride + p*R + bitrev_r(k1)]
+template <int LOGR>
+__global__ __launch_bounds__(256) void k_ntt_outer_fwd(const u64* __restrict__ z, size_t N, u64* __restrict__ out,
+                                                       size_t out_stride, const u64* __restrict__ wn_pow_br /* w_N^bitrev16(p) */,
+                                                       u64 shift) {
+  constexpr int R = 1 << LOGR;
+  const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const u64* c = z + (size_t)blockIdx.y * N;
+  u64 x[R];
+  const u64 b = gl_mul(shift, wn_pow_br[p]);
+  u64 f = 1;
+#pragma unroll
+  for (int i1 = 0; i1 < R; i1++) {
+    u64 v = c[(size_t)i1 * NTT_N + p];
+    x[i1] = i1 ? gl_mul(v, f) : v;
+    f = gl_mul(f, b);
+  }
+  dft_small<LOGR, false>(x);
+  u64* o = out + (size_t)blockIdx.y * out_stride + p * R;
+#pragma unroll
+  for (int q = 0; q < R; q += 2) {
+    ulonglong2 w2;
+    w2.x = x[q];
+    w2.y = x[q + 1];
+    *reinterpret_cast<ulonglong2*>(o + q) = w2;
+  }
+}
+
+// c[col][k1][k2] *= shift^-(k1 + R k2)   (coset_ifft post-scaling in the transposed layout)
+__global__ __launch_bounds__(256) void k_coset_unscale(u64* __restrict__ c, size_t N, unsigned log_r, u64 shift_inv) {
+  const size_t pos = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (pos >= N) return;
+  const size_t k1 = pos >> 16, k2 = pos & (NTT_N - 1);
+  const u64 k = k1 + (k2 << log_r);
+  u64* col = c + (size_t)blockIdx.y * N;
+  col[pos] = gl_mul(col[pos], gl_pow(shift_inv, k));
+}
+
+int ntt_tall_tables_init(NttTallTables* T, unsigned log_n) {
+  const unsigned log_r = log_n - 16;
+  const size_t N = (size_t)1 << log_n, R = (size_t)1 << log_r;
+  std::vector<u64> h;
+  auto upload = [&](u64** dst, const std::vector<u64>& src) -> int {
+    if (hipMalloc((void**)dst, src.size() * 8) != hipSuccess) return -1;
+    if (hipMemcpy(*dst, src.data(), src.size() * 8, hipMemcpyHostToDevice) != hipSuccess) return -1;
+    return 0;
+  };
+  T->log_n = log_n;
+  const u64 wN = gl_root_of_unity(log_n), wNi = gl_inv(wN);
+  fill_pow_table(h, wNi, NTT_N);
+  if (upload(&T->wn_inv_pow, h)) return -1;
+  {
+    std::vector<u64> nat;
+    fill_pow_table(nat, wN, NTT_N);
+    h.resize(NTT_N);
+    for (size_t p = 0; p < NTT_N; p++) h[p] = nat[bitrev32((u32)p, 16)];
+    if (upload(&T->wn_pow_br, h)) return -1;
+  }
+  const u64 w2N = gl_root_of_unity(log_n + 1);
+  T->shift[0] = GL_GEN;
+  T->shift[1] = gl_mul(GL_GEN, w2N);
+  for (int hh = 0; hh < 2; hh++) {
+    fill_pow_table(h, gl_pow(T->shift[hh], R), NTT_N);  // (shift^R)^i2: coset of the block transforms
+    if (upload(&T->block_coset_pow[hh], h)) return -1;
+  }
+  T->r_inv = gl_inv((u64)R);
+  (void)N;
+  return 0;
+}
+void ntt_tall_tables_free(NttTallTables* T) {
+  hipFree(T->wn_inv_pow);
+  hipFree(T->wn_pow_br);
+  hipFree(T->block_coset_pow[0]);
+  hipFree(T->block_coset_pow[1]);
+}
+
+template <int LOGR>
+static void outer_inv_launch(const u64* in, u64* out, size_t N, const NttTallTables* TT, int ncols, hipStream_t s) {
+  k_ntt_outer_inv<LOGR><<<dim3(NTT_N / 256, ncols), 256, 0, s>>>(in, out, N, TT->wn_inv_pow, TT->r_inv);
+}
+template <int LOGR>
+static void outer_fwd_launch(const u64* z, size_t N, u64* out, size_t out_stride, const NttTallTables* TT, int h, int ncols,
+                             hipStream_t s) {
+  k_ntt_outer_fwd<LOGR><<<dim3(NTT_N / 256, ncols), 256, 0, s>>>(z, N, out, out_stride, TT->wn_pow_br, TT->shift[h]);
+}
+
+// values[C][N] natural -> coefficients[C][N] in the transposed layout; may run in place; tmp[C][N].
+void ntt_inverse_tall(const NttTables* T, const NttTallTables* TT, const u64* values, u64* coeffs, u64* tmp, int ncols,
+                      hipStream_t s) {
+  const unsigned log_r = TT->log_n - 16;
+  const size_t N = (size_t)1 << TT->log_n;
+  switch (log_r) {
+    case 1: outer_inv_launch<1>(values, coeffs, N, TT, ncols, s); break;
+    case 2: outer_inv_launch<2>(values, coeffs, N, TT, ncols, s); break;
+    case 3: outer_inv_launch<3>(values, coeffs, N, TT, ncols, s); break;
+    default: outer_inv_launch<4>(values, coeffs, N, TT, ncols, s); break;
+  }
+  dim3 grid(16, (unsigned)(ncols << log_r)), block(256);
+  k_ntt_pass1<true><<<grid, block, 0, s>>>(coeffs, N, tmp, N, nullptr, T->twmat_inv, T->tw256_inv, log_r);
+  k_ntt_pass2<true, false><<<grid, block, 0, s>>>(tmp, N, coeffs, N, nullptr, T->n_inv, T->tw256_inv, log_r);
+}
+// values on coset h (natural) -> transposed coefficients of the interpolant
+void ntt_coset_inverse_tall(const NttTables* T, const NttTallTables* TT, int h, const u64* values, u64* coeffs, u64* tmp, int ncols,
+                            hipStream_t s) {
+  ntt_inverse_tall(T, TT, values, coeffs, tmp, ncols, s);
+  const size_t N = (size_t)1 << TT->log_n;
+  k_coset_unscale<<<dim3((unsigned)(N / 256), ncols), 256, 0, s>>>(coeffs, N, TT->log_n - 16, gl_inv(TT->shift[h]));
+}
+// transposed coefficients[C][N] -> lde[C][2N] bit-reversed; tmp[C][N].
+void ntt_lde_tall(const NttTables* T, const NttTallTables* TT, const u64* coeffs, u64* lde, u64* tmp, int ncols, hipStream_t s) {
+  const unsigned log_r = TT->log_n - 16;
+  const size_t N = (size_t)1 << TT->log_n;
+  dim3 grid(16, (unsigned)(ncols << log_r)), block(256);
+  for (int h = 0; h < 2; h++) {
+    u64* half = lde + (size_t)h * N;
+    k_ntt_pass1<false><<<grid, block, 0, s>>>(coeffs, N, half, 2 * N, TT->block_coset_pow[h], T->twmat_fwd, T->tw256_fwd, log_r);
+    k_ntt_pass2<false, true><<<grid, block, 0, s>>>(half, 2 * N, tmp, N, nullptr, 1, T->tw256_fwd, log_r);
+    switch (log_r) {
+      case 1: outer_fwd_launch<1>(tmp, N, half, 2 * N, TT, h, ncols, s); break;
+      case 2: outer_fwd_launch<2>(tmp, N, half, 2 * N, TT, h, ncols, s); break;
+      case 3: outer_fwd_launch<3>(tmp, N, half, 2 * N, TT, h, ncols, s); break;
+      default: outer_fwd_launch<4>(tmp, N, half, 2 * N, TT, h, ncols, s); break;
+    }
+  }
 }

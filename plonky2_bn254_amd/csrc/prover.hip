@@ -97,6 +97,21 @@ __global__ __launch_bounds__(256) void k_quotient_chunks(const u64* __restrict__
     }                                                          \
   } while (0)
 
+// Per-degree tables of the tall-trace NTT, built on first use.
+static const NttTallTables* get_tall_tables(bn254s_ctx* c, unsigned log_n) {
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lk(mu);
+  auto it = c->tall.find(log_n);
+  if (it != c->tall.end()) return it->second;
+  NttTallTables* t = new NttTallTables();
+  if (ntt_tall_tables_init(t, log_n) != 0) {
+    delete t;
+    return nullptr;
+  }
+  c->tall[log_n] = t;
+  return t;
+}
+
 // Holds the context's big-kernel lock; on release waits until the slot's stream has drained.
 struct BigSection {
   bn254s_ctx* c;
@@ -133,8 +148,10 @@ static int prove_on_slot(bn254s_ctx* c, Slot& sl, int kind, const bn254s_params&
   const StarkShape sh = shape_for(kind);
   const int PW = point_words(kind);
   const size_t N = rows_for(n, P.min_rows_log2);
-  if (N != NTT_N) {
-    err = "this build proves 2^16-row traces only (<= 128 instances per proof); cut larger batches into several proofs";
+  unsigned log_n = 0;
+  while (((size_t)1 << log_n) < N) log_n++;
+  if (log_n < 16 || log_n > 20) {
+    err = "supported trace heights: 2^16 .. 2^20 rows (up to 2048 instances in one proof)";
     return BN254S_E_UNSUPPORTED;
   }
   if (P.num_challenges != 2 || P.rate_bits != 1 || P.cap_height != 4 || P.arity_bits != 4 || P.min_rows_log2 < 16 ||
@@ -142,17 +159,36 @@ static int prove_on_slot(bn254s_ctx* c, Slot& sl, int kind, const bn254s_params&
     err = "unsupported StarkConfig (only standard_fast_config shapes)";
     return BN254S_E_UNSUPPORTED;
   }
-  const unsigned log_n = 16, log_m2 = 17;
+  const unsigned log_m2 = log_n + 1, log_r = log_n - 16;
+  const size_t R = (size_t)1 << log_r;
   const size_t M2 = 2 * N;
   const int W = sh.W, A = sh.n_aux(), NQ = 4, CAPW = 64;
   const int K = sh.n_total_constraints();
   hipStream_t st = sl.st;
   BufPool& mem = sl.mem;
+  u64* d_tmp_fwd = nullptr;  // = d_tmp once the workspace is set up (used by the NTT dispatch lambdas)
   QPointTables pt;
   if (int rc = get_point_tables(c, log_n, pt)) {
     err = "point tables";
     return rc;
   }
+  const NttTallTables* TT = nullptr;
+  if (log_r) {
+    TT = get_tall_tables(c, log_n);
+    if (!TT) {
+      err = "tall NTT tables";
+      return BN254S_E_OOM;
+    }
+  }
+  // iNTT / LDE / coset iNTT dispatch: 2^16-row traces use the four-step kernels directly, taller ones add the outer pass
+  auto do_intt = [&](const u64* vals, u64* coef, int nc) {
+    if (log_r) ntt_inverse_tall(&c->ntt, TT, vals, coef, d_tmp_fwd, nc, st);
+    else ntt_inverse(&c->ntt, vals, coef, d_tmp_fwd, nc, st);
+  };
+  auto do_lde = [&](const u64* coef, u64* lde, int nc) {
+    if (log_r) ntt_lde_tall(&c->ntt, TT, coef, lde, d_tmp_fwd, nc, st);
+    else ntt_lde(&c->ntt, coef, lde, d_tmp_fwd, nc, st);
+  };
   const std::vector<int> arities = fri_arities(P, log_n);
   const int L = (int)arities.size();
   if (L > FRI_MAX_LAYERS) return BN254S_E_UNSUPPORTED;
@@ -163,6 +199,7 @@ static int prove_on_slot(bn254s_ctx* c, Slot& sl, int kind, const bn254s_params&
   u64* d_tvals = mem.words("tvals", (size_t)W * N);
   u64* d_tcoef = mem.words("tcoef", (size_t)W * N);
   u64* d_tmp = mem.words("tmp", (size_t)std::max(W, A) * N);
+  d_tmp_fwd = d_tmp;
   u64* d_tlde = mem.words("tlde", (size_t)W * M2);
   const size_t tree_words = merkle_tree_digests(log_m2, P.cap_height) * 4;
   u64* d_trees = mem.words("trees", 3 * tree_words);
@@ -173,7 +210,7 @@ static int prove_on_slot(bn254s_ctx* c, Slot& sl, int kind, const bn254s_params&
   u64* d_scr = mem.words("scratch", std::max(trace_scr, aux_scratch_words(sh, N)));
   u64* d_q = mem.words("quot", (size_t)(3 * NQ) * N + (size_t)NQ * M2 + (size_t)QUOTIENT_MAX_PARTS * 2 * M2);  // qv, ab, qcoef, qlde, partials
   u64* d_tabs = mem.words("tabs", 2 * (size_t)K + 10 * 2 * 80 + 2 * (size_t)(W + A + NQ));
-  u64* d_open = mem.words("open", (size_t)(W + A + NQ) * 5);
+  u64* d_open = mem.words("open", std::max((size_t)(W + A + NQ) * R * 5, n * (size_t)PW));
   // FRI layer values (extension, 2 words) and trees
   size_t fri_words = 0, fri_tree_words = 0;
   {
@@ -254,8 +291,8 @@ static int prove_on_slot(bn254s_ctx* c, Slot& sl, int kind, const bn254s_params&
   {
     BigSection big(c, st);
     sb(ST_TRACE_NTT);
-    ntt_inverse(&c->ntt, d_tvals, d_tcoef, d_tmp, W, st);
-    ntt_lde(&c->ntt, d_tcoef, d_tlde, d_tmp, W, st);
+    do_intt(d_tvals, d_tcoef, W);
+    do_lde(d_tcoef, d_tlde, W);
     se(ST_TRACE_NTT);
   }
   {
@@ -292,8 +329,8 @@ static int prove_on_slot(bn254s_ctx* c, Slot& sl, int kind, const bn254s_params&
     aux_build(sh, d_tvals, N, betas, gammas, d_avals, d_scr, d_err, st);
     se(ST_AUX);
     sb(ST_AUX_NTT);
-    ntt_inverse(&c->ntt, d_avals, d_acoef, d_tmp, A, st);
-    ntt_lde(&c->ntt, d_acoef, d_alde, d_tmp, A, st);
+    do_intt(d_avals, d_acoef, A);
+    do_lde(d_acoef, d_alde, A);
     se(ST_AUX_NTT);
   }
   {
@@ -330,7 +367,8 @@ static int prove_on_slot(bn254s_ctx* c, Slot& sl, int kind, const bn254s_params&
   }
   for (int a = 0; a < 2; a++)
     for (int h = 0; h < 2; h++)
-      ntt_coset_inverse(&c->ntt, h, d_qv + (size_t)(a * 2 + h) * N, d_ab + (size_t)(a * 2 + h) * N, d_tmp, 1, st);
+      if (log_r) ntt_coset_inverse_tall(&c->ntt, TT, h, d_qv + (size_t)(a * 2 + h) * N, d_ab + (size_t)(a * 2 + h) * N, d_tmp, 1, st);
+      else ntt_coset_inverse(&c->ntt, h, d_qv + (size_t)(a * 2 + h) * N, d_ab + (size_t)(a * 2 + h) * N, d_tmp, 1, st);
   {
     u64 gn = gl_pow(GL_GEN, N);
     u64 inv2 = gl_inv(2), inv2c = gl_inv(gl_mul(2, gn));
@@ -339,7 +377,7 @@ static int prove_on_slot(bn254s_ctx* c, Slot& sl, int kind, const bn254s_params&
   }
   se(ST_QUOTIENT);
   sb(ST_QUOTIENT_COMMIT);
-  ntt_lde(&c->ntt, d_qcoef, d_qlde, d_tmp, NQ, st);
+  do_lde(d_qcoef, d_qlde, NQ);
   merkle_build(d_qlde, 1, M2, NQ, log_m2, P.cap_height, d_qtree, st);
   CHK(hipMemcpyAsync(caps[2], d_qtree + cap_off, CAPW * 8, hipMemcpyDeviceToHost, st));
   se(ST_QUOTIENT_COMMIT);
@@ -362,14 +400,36 @@ static int prove_on_slot(bn254s_ctx* c, Slot& sl, int kind, const bn254s_params&
   {
     BigSection big(c, st);
     sb(ST_OPENINGS);
-    fri_openings(d_tcoef, N, W, zeta, zeta_next, d_open, st);
-    fri_openings(d_acoef, N, A, zeta, zeta_next, d_open + (size_t)W * 5, st);
-    fri_openings(d_qcoef, N, NQ, zeta, zeta_next, d_open + (size_t)(W + A) * 5, st);
+    fri_openings(d_tcoef, N, log_r, W, zeta, zeta_next, d_open, st);
+    fri_openings(d_acoef, N, log_r, A, zeta, zeta_next, d_open + (size_t)W * R * 5, st);
+    fri_openings(d_qcoef, N, log_r, NQ, zeta, zeta_next, d_open + (size_t)(W + A) * R * 5, st);
   }
-  std::vector<u64> h_open((size_t)(W + A + NQ) * 5);
-  CHK(hipMemcpyAsync(h_open.data(), d_open, h_open.size() * 8, hipMemcpyDeviceToHost, st));
+  std::vector<u64> h_part((size_t)(W + A + NQ) * R * 5), h_open((size_t)(W + A + NQ) * 5);
+  CHK(hipMemcpyAsync(h_part.data(), d_open, h_part.size() * 8, hipMemcpyDeviceToHost, st));
   se(ST_OPENINGS);
   CHK(hipStreamSynchronize(st));
+  {  // P(z) = sum_k1 z^k1 S_k1(z^R) (transposed coefficient layout); P(1) = sum of the block sums
+    std::vector<gl2> zp0(R), zp1(R);
+    gl2 a = gl2_make(1, 0), b = gl2_make(1, 0);
+    for (size_t k1 = 0; k1 < R; k1++) {
+      zp0[k1] = a;
+      zp1[k1] = b;
+      a = gl2_mul(a, zeta);
+      b = gl2_mul(b, zeta_next);
+    }
+    for (int p = 0; p < W + A + NQ; p++) {
+      gl2 v0 = gl2_make(0, 0), v1 = gl2_make(0, 0);
+      u64 s1 = 0;
+      for (size_t k1 = 0; k1 < R; k1++) {
+        const u64* q = &h_part[((size_t)p * R + k1) * 5];
+        v0 = gl2_add(v0, gl2_mul(zp0[k1], gl2_make(q[0], q[1])));
+        v1 = gl2_add(v1, gl2_mul(zp1[k1], gl2_make(q[2], q[3])));
+        s1 = gl_add(s1, q[4]);
+      }
+      u64* o5 = &h_open[(size_t)p * 5];
+      o5[0] = v0.c0; o5[1] = v0.c1; o5[2] = v1.c0; o5[3] = v1.c1; o5[4] = s1;
+    }
+  }
   const int num_lookup = sh.n_lookup_cols(), n_ctlz = 2 * sh.n_ctl;
   auto op = [&](int p, int k) { return h_open[(size_t)p * 5 + k]; };
   // to_fri_openings order: (local | aux | quotient) at zeta, (next | aux_next) at g*zeta, ctl_zs_first
