@@ -73,8 +73,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    import plonky2_bn254_amd as pk   # first: sets GPU_MAX_HW_QUEUES before the HIP runtime initialises
     import torch
-    import plonky2_bn254_amd as pk
     from plonky2_bn254_amd import synth
 
     rank = int(os.environ.get("RANK", "0"))

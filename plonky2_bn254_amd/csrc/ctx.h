@@ -46,6 +46,8 @@ struct Slot {
   size_t pinned_bytes = 0;
 };
 
+enum { BIG_NTT = 0, BIG_EXCL = 1, BIG_HASH = 2 };
+
 struct bn254s_ctx : BufPool {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -57,24 +59,22 @@ struct bn254s_ctx : BufPool {
   // kernels (EC chain, upper Merkle levels, scans, PoW) run outside it and overlap freely.
   std::mutex big_mu;
   std::condition_variable big_cv;
-  int big_excl = 0, big_shared = 0;  // holders of the exclusive class / of the shared (hash) class
-  // Exclusive sections (NTT, quotient, openings, FRI combine) run alone; the Poseidon leaf-hash kernels of up to
-  // two proofs may run side by side (one 2^17-leaf launch puts only two waves on a SIMD).
-  void big_lock(bool shared) {
+  // Weighted semaphore over the GPU-filling sections of all proofs in flight.  Classes (cost out of big_cap = 3):
+  //   BIG_NTT  (3): the NTT/LDE stage runs alone - it is the stage the roofline figure is quoted on;
+  //   BIG_EXCL (2): quotient, auxiliary columns, openings, FRI combine - one at a time, but a leaf-hash launch may fill
+  //                 the SIMDs beside it;
+  //   BIG_HASH (1): Poseidon leaf hashing - one 2^17-leaf launch puts only two waves on a SIMD, up to three run together.
+  // BN254S_BIG_CAP / BN254S_BIG_COST_NTT / BN254S_BIG_COST_EXCL / BN254S_BIG_COST_HASH override the costs (tuning only).
+  int big_cap = 3, big_cost[3] = {3, 2, 1}, big_used = 0;
+  void big_lock(int cls) {
     std::unique_lock<std::mutex> lk(big_mu);
-    if (shared) {
-      big_cv.wait(lk, [&] { return big_excl == 0 && big_shared < 2; });
-      big_shared++;
-    } else {
-      big_cv.wait(lk, [&] { return big_excl == 0 && big_shared == 0; });
-      big_excl = 1;
-    }
+    big_cv.wait(lk, [&] { return big_used + big_cost[cls] <= big_cap; });
+    big_used += big_cost[cls];
   }
-  void big_unlock(bool shared) {
+  void big_unlock(int cls) {
     {
       std::lock_guard<std::mutex> lk(big_mu);
-      if (shared) big_shared--;
-      else big_excl = 0;
+      big_used -= big_cost[cls];
     }
     big_cv.notify_all();
   }

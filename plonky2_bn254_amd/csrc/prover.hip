@@ -116,11 +116,11 @@ static const NttTallTables* get_tall_tables(bn254s_ctx* c, unsigned log_n) {
 struct BigSection {
   bn254s_ctx* c;
   hipStream_t st;
-  bool shared;
-  BigSection(bn254s_ctx* c_, hipStream_t st_, bool shared_ = false) : c(c_), st(st_), shared(shared_) { c->big_lock(shared); }
+  int cls;
+  BigSection(bn254s_ctx* c_, hipStream_t st_, int cls_) : c(c_), st(st_), cls(cls_) { c->big_lock(cls); }
   ~BigSection() {
     hipStreamSynchronize(st);
-    c->big_unlock(shared);
+    c->big_unlock(cls);
   }
 };
 
@@ -289,14 +289,14 @@ static int prove_on_slot(bn254s_ctx* c, Slot& sl, int kind, const bn254s_params&
 
   // ---- trace commitment (prover.rs:31-38) -----------------------------------------------------------------
   {
-    BigSection big(c, st);
+    BigSection big(c, st, BIG_NTT);
     sb(ST_TRACE_NTT);
     do_intt(d_tvals, d_tcoef, W);
     do_lde(d_tcoef, d_tlde, W);
     se(ST_TRACE_NTT);
   }
   {
-    BigSection big(c, st, true);
+    BigSection big(c, st, BIG_HASH);
     sb(ST_TRACE_MERKLE);
     merkle_leaves(d_tlde, 1, M2, W, log_m2, d_ttree, st);
   }
@@ -324,17 +324,20 @@ static int prove_on_slot(bn254s_ctx* c, Slot& sl, int kind, const bn254s_params&
 
   // ---- auxiliary columns + commitment ---------------------------------------------------------------------
   {
-    BigSection big(c, st);
+    BigSection big(c, st, BIG_EXCL);
     sb(ST_AUX);
     aux_build(sh, d_tvals, N, betas, gammas, d_avals, d_scr, d_err, st);
     se(ST_AUX);
+  }
+  {
+    BigSection big(c, st, BIG_NTT);
     sb(ST_AUX_NTT);
     do_intt(d_avals, d_acoef, A);
     do_lde(d_acoef, d_alde, A);
     se(ST_AUX_NTT);
   }
   {
-    BigSection big(c, st, true);
+    BigSection big(c, st, BIG_HASH);
     sb(ST_AUX_MERKLE);
     merkle_leaves(d_alde, 1, M2, A, log_m2, d_atree, st);
   }
@@ -357,7 +360,7 @@ static int prove_on_slot(bn254s_ctx* c, Slot& sl, int kind, const bn254s_params&
     CHK(hipStreamSynchronize(st));  // host vectors go out of scope
   }
   {
-    BigSection big(c, st);
+    BigSection big(c, st, BIG_EXCL);
     sb(ST_QUOTIENT);
     QArgs QA;
     quotient_fill_args(QA, sh, d_tlde, d_alde, d_W, d_mzt, pt, betas, gammas, log_n, d_qv, d_qpart);
@@ -398,7 +401,7 @@ static int prove_on_slot(bn254s_ctx* c, Slot& sl, int kind, const bn254s_params&
 
   // ---- openings (StarkOpeningSet::new) ---------------------------------------------------------------------
   {
-    BigSection big(c, st);
+    BigSection big(c, st, BIG_EXCL);
     sb(ST_OPENINGS);
     fri_openings(d_tcoef, N, log_r, W, zeta, zeta_next, d_open, st);
     fri_openings(d_acoef, N, log_r, A, zeta, zeta_next, d_open + (size_t)W * R * 5, st);
@@ -461,7 +464,7 @@ static int prove_on_slot(bn254s_ctx* c, Slot& sl, int kind, const bn254s_params&
     }
     CHK(hipMemcpyAsync(d_apow, apow.data(), apow.size() * 8, hipMemcpyHostToDevice, st));
     CHK(hipStreamSynchronize(st));
-    BigSection big(c, st);
+    BigSection big(c, st, BIG_EXCL);
     sb(ST_FRI);
     fri_combine(sh, d_tlde, d_alde, d_qlde, d_apow, pt.x, zeta, zeta_next, r0, r1, r2, fri_alpha, M2, d_fri, st);
   }
