@@ -9,12 +9,13 @@
 //   generate_round_flags (src/starks/common/round_flags.rs:21-44), generate_range_checks (:71-87).
 // Column layout: src/starks/curves/g1/scalar_mul_view.rs:34-49 (see trace_g1.h).
 //
-// Phase A (sequential per instance, no inversions): double-and-add chain in Jacobian coordinates, every
-// intermediate point (offset, C_k = S_{k-1} + D_k, D_k = 2^k x) is stored.  Phase A' : all Z are inverted
-// with Montgomery's batch trick.  Phase B (one thread per trace row): affine a, b, c, lambda and the limb /
+// Phase A (no inversions, Jacobian coordinates): the 256 doublings D_k = 2^k x are the only sequential part (one lane per
+// instance); the running sums S_k and C_k = S_k + D_k come from a 256-lane prefix scan per instance (chain_scan.h).
+// Every intermediate point (offset, C_k, D_k) is stored.  Phase A': all Z are inverted with Montgomery's batch trick.  Phase B (one thread per trace row): affine a, b, c, lambda and the limb /
 // quotient / carry witnesses; the exact division by p is a multiplication by p^-1 mod 2^288.
 // The trace is written column-major (trace[c*N + row]), so consecutive lanes write consecutive words.
 #include "trace_common.h"
+#include "chain_scan.h"
 #include "trace_g1.h"
 
 // ---- batched field inversion ------------------------------------------------------------------------------
@@ -119,39 +120,66 @@ void launch_range_columns(u64* trace, size_t N, int rc_begin, int rc_end, int fr
 }
 
 
-// ---- phase A: the chain -----------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_g1_chain(const u64* __restrict__ scalars, const u64* __restrict__ xs,
-                                                 const u64* __restrict__ offs, int n, u64* __restrict__ px,
-                                                 u64* __restrict__ py, u64* __restrict__ pz, int* __restrict__ err) {
+// ---- phase A: doubling chain (sequential) + running sums (parallel scan, chain_scan.h) -----------------------------
+__global__ __launch_bounds__(64) void k_g1_dbl_chain(const u64* __restrict__ xs, int n, u64* __restrict__ px, u64* __restrict__ py,
+                                                     u64* __restrict__ pz) {
   int inst = blockIdx.x * blockDim.x + threadIdx.x;
   if (inst >= n) return;
   size_t cnt = (size_t)NPTS * n;
-  u64 s[4];
-  for (int i = 0; i < 4; i++) s[i] = scalars[4 * inst + i];
-  g1j S, D;
+  g1j D;
   D.x = fq_from_canonical(xs + 8 * inst);
   D.y = fq_from_canonical(xs + 8 * inst + 4);
   D.z = fq_one();
-  S.x = fq_from_canonical(offs + 8 * inst);
-  S.y = fq_from_canonical(offs + 8 * inst + 4);
-  S.z = fq_one();
+#pragma unroll 1
+  for (int k = 0; k <= 256; k++) {
+    size_t e = (size_t)(257 + k) * n + inst;
+    st_fq(px, cnt, e, D.x);
+    st_fq(py, cnt, e, D.y);
+    st_fq(pz, cnt, e, D.z);
+    if (k < 256) D = g1_double(D);
+  }
+}
+
+// one workgroup per instance, lane k: S_k = offset + sum_{j<k, bit_j} D_j, then C_k = S_k + D_k
+__global__ __launch_bounds__(256) void k_g1_sum_scan(const u64* __restrict__ scalars, const u64* __restrict__ offs, int n,
+                                                     u64* __restrict__ px, u64* __restrict__ py, u64* __restrict__ pz,
+                                                     int* __restrict__ err) {
+  __shared__ u64 sh[12 * 256];
+  const int inst = blockIdx.x, k = threadIdx.x;
+  const size_t cnt = (size_t)NPTS * n;
+  auto load = [&](int pt) {
+    size_t e = (size_t)pt * n + inst;
+    g1j p;
+    p.x = ld_fq(px, cnt, e);
+    p.y = ld_fq(py, cnt, e);
+    p.z = ld_fq(pz, cnt, e);
+    return p;
+  };
   auto store = [&](int pt, const g1j& p) {
     size_t e = (size_t)pt * n + inst;
     st_fq(px, cnt, e, p.x);
     st_fq(py, cnt, e, p.y);
     st_fq(pz, cnt, e, p.z);
   };
-  store(0, S);
-  for (int k = 0; k < 256; k++) {
-    g1j C;
-    int rc = g1_add(S, D, C);
-    if (rc == 2) atomicCAS(err, 0, BN254S_E_INVALID_POINT);
-    store(1 + k, C);
-    store(257 + k, D);
-    if ((s[k >> 6] >> (k & 63)) & 1) S = C;
-    D = g1_double(D);
+  g1j f;
+  if (k == 0) {
+    f.x = fq_from_canonical(offs + 8 * inst);
+    f.y = fq_from_canonical(offs + 8 * inst + 4);
+    f.z = fq_one();
+    store(0, f);
+  } else {
+    const int j = k - 1;
+    const bool bit = (scalars[4 * inst + (j >> 6)] >> (j & 63)) & 1;
+    f = bit ? load(257 + j) : pt_infinity((const g1j*)nullptr);
   }
-  store(513, D);
+  pt_scan256(f, sh, k);
+  g1j d = load(257 + k), c;
+  if (pt_inf(f)) {
+    c = d;  // only after an S_j = -D_j further down, which is reported there
+  } else if (g1_add(f, d, c) == 2) {
+    atomicCAS(err, 0, BN254S_E_INVALID_POINT);
+  }
+  store(1 + k, c);
 }
 
 // ---- phase B helpers ------------------------------------------------------------------------------------------
@@ -352,7 +380,8 @@ int g1_generate_trace_device(const u64* d_scalars, const u64* d_x, const u64* d_
   u32* hist = (u32*)(rf + 1024);
   if (nrows < N) hipMemsetAsync(d_trace, 0, (size_t)G1_W * N * 8, st);
   launch_round_flag_table(rf, st);
-  k_g1_chain<<<(unsigned)((n + 63) / 64), 64, 0, st>>>(d_scalars, d_x, d_off, (int)n, px, py, pz, d_err);
+  k_g1_dbl_chain<<<(unsigned)((n + 63) / 64), 64, 0, st>>>(d_x, (int)n, px, py, pz);
+  k_g1_sum_scan<<<(unsigned)n, 256, 0, st>>>(d_scalars, d_off, (int)n, px, py, pz, d_err);
   launch_fq_batch_inv(pz, zi, cnt, st);
   k_g1_row_den<<<(unsigned)((nrows + 63) / 64), 64, 0, st>>>(d_scalars, (int)n, px, py, zi, den);
   launch_fq_batch_inv(den, deninv, nrows, st);

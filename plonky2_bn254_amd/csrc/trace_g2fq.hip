@@ -9,6 +9,7 @@
 // Same structure as trace_g1.hip: a sequential inversion-free chain per instance, Montgomery batch inversion,
 // then one lane per trace row.
 #include "trace_common.h"
+#include "chain_scan.h"
 #include "trace_g2fq.h"
 
 // ======================================== G2 ==================================================================
@@ -32,21 +33,40 @@ __device__ __forceinline__ fq2 fq2_from_canonical(const u64* w) {
   return r;
 }
 
-__global__ __launch_bounds__(64) void k_g2_chain(const u64* __restrict__ scalars, const u64* __restrict__ xs,
-                                                 const u64* __restrict__ offs, int n, Soa2 px, Soa2 py, Soa2 pz, u64* __restrict__ znorm,
-                                                 int* __restrict__ err) {
+// phase A as in trace_g1.hip: sequential doubling chain, then the running sums by a parallel scan (chain_scan.h)
+__global__ __launch_bounds__(64) void k_g2_dbl_chain(const u64* __restrict__ xs, int n, Soa2 px, Soa2 py, Soa2 pz,
+                                                     u64* __restrict__ znorm) {
   int inst = blockIdx.x * blockDim.x + threadIdx.x;
   if (inst >= n) return;
   size_t cnt = (size_t)NPTS * n;
-  u64 s[4];
-  for (int i = 0; i < 4; i++) s[i] = scalars[4 * inst + i];
-  g2j S, D;
+  g2j D;
   D.x = fq2_from_canonical(xs + 16 * inst);
   D.y = fq2_from_canonical(xs + 16 * inst + 8);
   D.z = fq2_one();
-  S.x = fq2_from_canonical(offs + 16 * inst);
-  S.y = fq2_from_canonical(offs + 16 * inst + 8);
-  S.z = fq2_one();
+#pragma unroll 1
+  for (int k = 0; k <= 256; k++) {
+    size_t e = (size_t)(257 + k) * n + inst;
+    st_fq2(px, cnt, e, D.x);
+    st_fq2(py, cnt, e, D.y);
+    st_fq2(pz, cnt, e, D.z);
+    st_fq(znorm, cnt, e, fq2_norm(D.z));
+    if (k < 256) D = g2_double(D);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_g2_sum_scan(const u64* __restrict__ scalars, const u64* __restrict__ offs, int n, Soa2 px,
+                                                     Soa2 py, Soa2 pz, u64* __restrict__ znorm, int* __restrict__ err) {
+  __shared__ u64 sh[24 * 256];
+  const int inst = blockIdx.x, k = threadIdx.x;
+  const size_t cnt = (size_t)NPTS * n;
+  auto load = [&](int pt) {
+    size_t e = (size_t)pt * n + inst;
+    g2j p;
+    p.x = ld_fq2(px, cnt, e);
+    p.y = ld_fq2(py, cnt, e);
+    p.z = ld_fq2(pz, cnt, e);
+    return p;
+  };
   auto store = [&](int pt, const g2j& p) {
     size_t e = (size_t)pt * n + inst;
     st_fq2(px, cnt, e, p.x);
@@ -54,17 +74,25 @@ __global__ __launch_bounds__(64) void k_g2_chain(const u64* __restrict__ scalars
     st_fq2(pz, cnt, e, p.z);
     st_fq(znorm, cnt, e, fq2_norm(p.z));
   };
-  store(0, S);
-  for (int k = 0; k < 256; k++) {
-    g2j C;
-    int rc = g2_add(S, D, C);
-    if (rc == 2) atomicCAS(err, 0, BN254S_E_INVALID_POINT);
-    store(1 + k, C);
-    store(257 + k, D);
-    if ((s[k >> 6] >> (k & 63)) & 1) S = C;
-    D = g2_double(D);
+  g2j f;
+  if (k == 0) {
+    f.x = fq2_from_canonical(offs + 16 * inst);
+    f.y = fq2_from_canonical(offs + 16 * inst + 8);
+    f.z = fq2_one();
+    store(0, f);
+  } else {
+    const int j = k - 1;
+    const bool bit = (scalars[4 * inst + (j >> 6)] >> (j & 63)) & 1;
+    f = bit ? load(257 + j) : pt_infinity((const g2j*)nullptr);
   }
-  store(513, D);
+  pt_scan256(f, sh, k);
+  g2j d = load(257 + k), c;
+  if (pt_inf(f)) {
+    c = d;
+  } else if (g2_add(f, d, c) == 2) {
+    atomicCAS(err, 0, BN254S_E_INVALID_POINT);
+  }
+  store(1 + k, c);
 }
 
 struct Aff2 {
@@ -310,7 +338,8 @@ int g2_generate_trace_device(const u64* d_scalars, const u64* d_x, const u64* d_
   u32* hist = (u32*)take(65536 / 2);
   if (nrows < N) hipMemsetAsync(d_trace, 0, (size_t)G2L::W * N * 8, st);
   launch_round_flag_table(rf, st);
-  k_g2_chain<<<(unsigned)((n + 63) / 64), 64, 0, st>>>(d_scalars, d_x, d_off, (int)n, px, py, pz, znorm, d_err);
+  k_g2_dbl_chain<<<(unsigned)((n + 63) / 64), 64, 0, st>>>(d_x, (int)n, px, py, pz, znorm);
+  k_g2_sum_scan<<<(unsigned)n, 256, 0, st>>>(d_scalars, d_off, (int)n, px, py, pz, znorm, d_err);
   launch_fq_batch_inv(znorm, zni, cnt, st);
   k_g2_row_den<<<(unsigned)((nrows + 63) / 64), 64, 0, st>>>(d_scalars, (int)n, px, py, pz, zni, inv_in);
   launch_fq_batch_inv(inv_in, inv_out, 3 * nrows, st);
