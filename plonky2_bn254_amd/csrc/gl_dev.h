@@ -49,7 +49,10 @@ GL_HD u64 gl_reduce128(u64 lo, u64 hi) {
   u64 r2 = r + GL_EPS;             // wrapped sum (+2^64) and r >= p (-p) are the same correction
   return (r < t1 || r >= GL_P) ? r2 : r;
 }
-GL_HD u64 gl_mul(u64 a, u64 b) { return gl_reduce128(a * b, gl_mulhi(a, b)); }
+GL_HD u64 gl_mul(u64 a, u64 b) {
+  unsigned __int128 x = (unsigned __int128)a * b;  // one 128-bit product: the compiler shares the partial products of lo and hi
+  return gl_reduce128((u64)x, (u64)(x >> 64));
+}
 GL_HD u64 gl_sqr(u64 a) { return gl_mul(a, a); }
 // a*b + c
 GL_HD u64 gl_mad(u64 a, u64 b, u64 c) { return gl_add(gl_mul(a, b), c); }

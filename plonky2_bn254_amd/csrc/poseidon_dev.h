@@ -27,19 +27,56 @@ GL_HD u64 poseidon_sbox(u64 x) {
 
 // MDS: out[r] = sum_i s[(i+r)%12]*C[i] + (r==0)*8*s[0], C = {17,15,41,16,2,28,13,13,39,18,34,20}.
 // Lanes are split in 32-bit halves so that the small-constant products accumulate without carries
-// (each half-sum < 2^42); one 128-bit reduction per output lane.
-GL_HD void poseidon_mds(u64 s[12]) {
-  const u32 C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
-  u64 lo[12], hi[12], out[12];
+// (each half-sum < 2^41); one reduction per output lane:
+//   al + ah 2^32 = al + ah_lo 2^32 + ah_hi 2^64 == al + ah_hi (2^32 - 1) + ah_lo 2^32   (mod p),
+// the first two terms stay below 2^42, and the last addition is canonicalised like gl_add (wrap and ">= p" are both "+ EPS").
+#if defined(__HIP_DEVICE_COMPILE__)
+// gfx950: every term is one v_mad_u64_u32 (32 x 32 + 64).  The constants 2, 8 and 16 are handed over in SGPRs the optimiser
+// cannot see through, otherwise it turns those products into 64-bit shifts that cost two extra moves each.
+__device__ __forceinline__ void poseidon_mds(u64 s[12]) {
+  u32 c2, c8, c16;
+  asm("s_mov_b32 %0, 2" : "=s"(c2));
+  asm("s_mov_b32 %0, 8" : "=s"(c8));
+  asm("s_mov_b32 %0, 16" : "=s"(c16));
+  const u32 C[12] = {17, 15, 41, c16, c2, 28, 13, 13, 39, 18, 34, 20};
+  u32 lo[12], hi[12];
+  u64 out[12];
 #pragma unroll
   for (int i = 0; i < 12; i++) {
-    lo[i] = s[i] & GL_EPS;
-    hi[i] = s[i] >> 32;
+    lo[i] = (u32)s[i];
+    hi[i] = (u32)(s[i] >> 32);
   }
 #pragma unroll
   for (int r = 0; r < 12; r++) {
     u64 al = 0, ah = 0;
 #pragma unroll
+    for (int i = 0; i < 12; i++) {
+      al += (u64)lo[(i + r) % 12] * C[i];
+      ah += (u64)hi[(i + r) % 12] * C[i];
+    }
+    if (r == 0) {
+      al += (u64)lo[0] * c8;
+      ah += (u64)hi[0] * c8;
+    }
+    u64 t = al + (u64)(u32)(ah >> 32) * 0xFFFFFFFFull;
+    u64 x = ah << 32;
+    u64 sum = t + x;
+    u64 sum2 = sum + GL_EPS;
+    out[r] = (sum < x || sum >= GL_P) ? sum2 : sum;
+  }
+#pragma unroll
+  for (int i = 0; i < 12; i++) s[i] = out[i];
+}
+#else
+inline void poseidon_mds(u64 s[12]) {
+  const u32 C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+  u64 lo[12], hi[12], out[12];
+  for (int i = 0; i < 12; i++) {
+    lo[i] = s[i] & GL_EPS;
+    hi[i] = s[i] >> 32;
+  }
+  for (int r = 0; r < 12; r++) {
+    u64 al = 0, ah = 0;
     for (int i = 0; i < 12; i++) {
       al += lo[(i + r) % 12] * C[i];
       ah += hi[(i + r) % 12] * C[i];
@@ -48,14 +85,13 @@ GL_HD void poseidon_mds(u64 s[12]) {
       al += lo[0] * 8;
       ah += hi[0] * 8;
     }
-    // value = al + ah*2^32 (< 2^75): lo64 = al + (ah<<32), hi = (ah>>32) + carry
     u64 l = al + (ah << 32);
     u64 h = (ah >> 32) + (l < al ? 1 : 0);
     out[r] = gl_reduce128(l, h);
   }
-#pragma unroll
   for (int i = 0; i < 12; i++) s[i] = out[i];
 }
+#endif
 
 GL_HD void poseidon_permute(u64 s[12]) {
   for (int rnd = 0; rnd < 30; rnd++) {
