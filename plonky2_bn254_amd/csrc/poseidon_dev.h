@@ -11,6 +11,10 @@ static const u64 POSEIDON_RC_HOST[360] = {
 static __constant__ u64 POSEIDON_RC_DEV[360] = {
 #include "poseidon_constants.inc"
 };
+// partial rounds: the constants of lanes 1..11 pushed through the linear layer (tools/derive_poseidon_constants.py)
+static __constant__ u64 POSEIDON_FOLD_DEV[22 * 24] = {
+#include "poseidon_partial_fold.inc"
+};
 
 GL_HD u64 poseidon_rc(int i) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -33,7 +37,8 @@ GL_HD u64 poseidon_sbox(u64 x) {
 #if defined(__HIP_DEVICE_COMPILE__)
 // gfx950: every term is one v_mad_u64_u32 (32 x 32 + 64).  The constants 2, 8 and 16 are handed over in SGPRs the optimiser
 // cannot see through, otherwise it turns those products into 64-bit shifts that cost two extra moves each.
-__device__ __forceinline__ void poseidon_mds(u64 s[12]) {
+// k != nullptr: the accumulators of output r start from k[2r], k[2r+1] (folded partial-round constants) instead of 0.
+__device__ __forceinline__ void poseidon_mds(u64 s[12], const u64* __restrict__ k = nullptr) {
   u32 c2, c8, c16;
   asm("s_mov_b32 %0, 2" : "=s"(c2));
   asm("s_mov_b32 %0, 8" : "=s"(c8));
@@ -46,23 +51,36 @@ __device__ __forceinline__ void poseidon_mds(u64 s[12]) {
     lo[i] = (u32)s[i];
     hi[i] = (u32)(s[i] >> 32);
   }
+  // four output lanes (eight independent accumulator chains) at a time: a single chain of dependent mads would leave the
+  // SIMD waiting on the multiplier's latency when only two waves are resident (2^17 leaves)
 #pragma unroll
-  for (int r = 0; r < 12; r++) {
-    u64 al = 0, ah = 0;
+  for (int r0 = 0; r0 < 12; r0 += 4) {
+    u64 al[4], ah[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      al[q] = k ? k[2 * (r0 + q)] : 0;
+      ah[q] = k ? k[2 * (r0 + q) + 1] : 0;
+    }
 #pragma unroll
     for (int i = 0; i < 12; i++) {
-      al += (u64)lo[(i + r) % 12] * C[i];
-      ah += (u64)hi[(i + r) % 12] * C[i];
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        al[q] += (u64)lo[(i + r0 + q) % 12] * C[i];
+        ah[q] += (u64)hi[(i + r0 + q) % 12] * C[i];
+      }
     }
-    if (r == 0) {
-      al += (u64)lo[0] * c8;
-      ah += (u64)hi[0] * c8;
+    if (r0 == 0) {
+      al[0] += (u64)lo[0] * c8;
+      ah[0] += (u64)hi[0] * c8;
     }
-    u64 t = al + (u64)(u32)(ah >> 32) * 0xFFFFFFFFull;
-    u64 x = ah << 32;
-    u64 sum = t + x;
-    u64 sum2 = sum + GL_EPS;
-    out[r] = (sum < x || sum >= GL_P) ? sum2 : sum;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      u64 t = al[q] + (u64)(u32)(ah[q] >> 32) * 0xFFFFFFFFull;
+      u64 x = ah[q] << 32;
+      u64 sum = t + x;
+      u64 sum2 = sum + GL_EPS;
+      out[r0 + q] = (sum < x || sum >= GL_P) ? sum2 : sum;
+    }
   }
 #pragma unroll
   for (int i = 0; i < 12; i++) s[i] = out[i];
@@ -93,18 +111,36 @@ inline void poseidon_mds(u64 s[12]) {
 }
 #endif
 
+#if defined(__HIP_DEVICE_COMPILE__)
+// a + b for canonical a, b, not canonicalised (any representative below 2^64): enough for the S-box and the MDS halves
+__device__ __forceinline__ u64 gl_add_lazy(u64 a, u64 b) {
+  u64 t = a + b;
+  return t < a ? t + GL_EPS : t;
+}
+#endif
 GL_HD void poseidon_permute(u64 s[12]) {
+#if defined(__HIP_DEVICE_COMPILE__)
   for (int rnd = 0; rnd < 30; rnd++) {
-#pragma unroll
-    for (int i = 0; i < 12; i++) s[i] = gl_add(s[i], poseidon_rc(12 * rnd + i));
     if (rnd < 4 || rnd >= 26) {
 #pragma unroll
+      for (int i = 0; i < 12; i++) s[i] = poseidon_sbox(gl_add_lazy(s[i], POSEIDON_RC_DEV[12 * rnd + i]));
+      poseidon_mds(s);
+    } else {
+      s[0] = poseidon_sbox(gl_add_lazy(s[0], POSEIDON_RC_DEV[12 * rnd]));
+      poseidon_mds(s, POSEIDON_FOLD_DEV + 24 * (rnd - 4));
+    }
+  }
+#else
+  for (int rnd = 0; rnd < 30; rnd++) {
+    for (int i = 0; i < 12; i++) s[i] = gl_add(s[i], poseidon_rc(12 * rnd + i));
+    if (rnd < 4 || rnd >= 26) {
       for (int i = 0; i < 12; i++) s[i] = poseidon_sbox(s[i]);
     } else {
       s[0] = poseidon_sbox(s[0]);
     }
     poseidon_mds(s);
   }
+#endif
 }
 
 GL_HD void poseidon_two_to_one(const u64 l[4], const u64 r[4], u64 out[4]) {
