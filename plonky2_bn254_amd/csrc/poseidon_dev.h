@@ -24,6 +24,31 @@ GL_HD u64 poseidon_rc(int i) {
 #endif
 }
 
+#if defined(__HIP_DEVICE_COMPILE__)
+// Inside the permutation the GPU keeps any representative below 2^64 (no ">= p" test after a product, a sum or an MDS fold):
+// products, the 32-bit halves of the MDS and gl_add_lazy accept such inputs, and the twelve lanes are canonicalised once at
+// the end of the permutation.
+__device__ __forceinline__ u64 gl_mul_lazy(u64 a, u64 b) {
+  unsigned __int128 x = (unsigned __int128)a * b;
+  u64 lo = (u64)x, hi = (u64)(x >> 64);
+  u64 hi_hi = hi >> 32, hi_lo = hi & GL_EPS;
+  u64 t0 = lo - hi_hi;
+  t0 = (lo < hi_hi) ? t0 - GL_EPS : t0;
+  u64 t1 = hi_lo * GL_EPS;
+  u64 r = t0 + t1;
+  return (r < t1) ? r + GL_EPS : r;
+}
+__device__ __forceinline__ u64 poseidon_sbox_lazy(u64 x) {
+  u64 x2 = gl_mul_lazy(x, x), x4 = gl_mul_lazy(x2, x2), x3 = gl_mul_lazy(x2, x);
+  return gl_mul_lazy(x3, x4);
+}
+// a + b, a any representative, b canonical; result any representative
+__device__ __forceinline__ u64 gl_add_lazy(u64 a, u64 b) {
+  u64 t = a + b;
+  return t < a ? t + GL_EPS : t;
+}
+#endif
+
 GL_HD u64 poseidon_sbox(u64 x) {
   u64 x2 = gl_sqr(x), x4 = gl_sqr(x2), x3 = gl_mul(x2, x);
   return gl_mul(x3, x4);
@@ -78,8 +103,7 @@ __device__ __forceinline__ void poseidon_mds(u64 s[12], const u64* __restrict__ 
       u64 t = al[q] + (u64)(u32)(ah[q] >> 32) * 0xFFFFFFFFull;
       u64 x = ah[q] << 32;
       u64 sum = t + x;
-      u64 sum2 = sum + GL_EPS;
-      out[r0 + q] = (sum < x || sum >= GL_P) ? sum2 : sum;
+      out[r0 + q] = (sum < x) ? sum + GL_EPS : sum;  // any representative; poseidon_permute canonicalises at the end
     }
   }
 #pragma unroll
@@ -111,25 +135,20 @@ inline void poseidon_mds(u64 s[12]) {
 }
 #endif
 
-#if defined(__HIP_DEVICE_COMPILE__)
-// a + b for canonical a, b, not canonicalised (any representative below 2^64): enough for the S-box and the MDS halves
-__device__ __forceinline__ u64 gl_add_lazy(u64 a, u64 b) {
-  u64 t = a + b;
-  return t < a ? t + GL_EPS : t;
-}
-#endif
 GL_HD void poseidon_permute(u64 s[12]) {
 #if defined(__HIP_DEVICE_COMPILE__)
   for (int rnd = 0; rnd < 30; rnd++) {
     if (rnd < 4 || rnd >= 26) {
 #pragma unroll
-      for (int i = 0; i < 12; i++) s[i] = poseidon_sbox(gl_add_lazy(s[i], POSEIDON_RC_DEV[12 * rnd + i]));
+      for (int i = 0; i < 12; i++) s[i] = poseidon_sbox_lazy(gl_add_lazy(s[i], POSEIDON_RC_DEV[12 * rnd + i]));
       poseidon_mds(s);
     } else {
-      s[0] = poseidon_sbox(gl_add_lazy(s[0], POSEIDON_RC_DEV[12 * rnd]));
+      s[0] = poseidon_sbox_lazy(gl_add_lazy(s[0], POSEIDON_RC_DEV[12 * rnd]));
       poseidon_mds(s, POSEIDON_FOLD_DEV + 24 * (rnd - 4));
     }
   }
+#pragma unroll
+  for (int i = 0; i < 12; i++) s[i] = s[i] >= GL_P ? s[i] - GL_P : s[i];
 #else
   for (int rnd = 0; rnd < 30; rnd++) {
     for (int i = 0; i < 12; i++) s[i] = gl_add(s[i], poseidon_rc(12 * rnd + i));
