@@ -65,12 +65,35 @@ def cpu_baseline():
             "sample": "1 proof of 128 G1 scalar-muls (2^16 rows), CPU restatement (oracle/), %.1f s" % dt}
 
 
+def other_kinds(ctx, synth):
+    """BASELINE.json configs[2] (1024 G2 scalar-muls) and the Fq-exp STARK of configs[4], same batch shape as the headline:
+    8 proofs x 128 instances on one GPU.  128 distinct synthetic instances are tiled 8x (python big-int G2 points are slow to
+    make); reported beside the headline, never part of `value`."""
+    res = {}
+    for name, kind, gen in (("g2_scalar_mul", 1, synth.g2_inputs), ("fq_exp", 2, synth.fq_inputs)):
+        try:
+            ins = [np.tile(a, (PROOFS_PER_STEP, 1)) for a in gen(INSTANCES_PER_PROOF)]
+            off = ins[2] if len(ins) > 2 else None
+            ctx.prove_batch(kind, ins[0], ins[1], off)
+            t0 = time.perf_counter()
+            reps = 2
+            for _ in range(reps):
+                ctx.prove_batch(kind, ins[0], ins[1], off)
+            dt = (time.perf_counter() - t0) / reps
+            res[name] = {"proofs_per_s": round(PROOFS_PER_STEP / dt, 2), "ms_per_batch_of_8": round(dt * 1e3, 1),
+                         "instances_per_s": round(PROOFS_PER_STEP * INSTANCES_PER_PROOF / dt, 1)}
+        except Exception as e:
+            res[name] = {"error": str(e)}
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the G2 / Fq-exp / tall-proof figures reported beside the headline")
     args = ap.parse_args()
 
     import plonky2_bn254_amd as pk   # first: sets GPU_MAX_HW_QUEUES before the HIP runtime initialises
@@ -153,6 +176,8 @@ def main():
         # circuit with 1024 calls; reported next to the headline, not part of `value`
         tall = None
         try:
+            if args.no_extras:
+                raise RuntimeError("skipped (--no-extras)")
             ctx.prove_g1(s, x, o)
             tt0 = time.perf_counter()
             ctx.prove_g1(s, x, o)
@@ -189,6 +214,8 @@ def main():
                                        "ms": round(excl_ms, 4),
                                        "note": "same six launches with no other stream on the GPU (bn254s_bench_ntt)"}},
         }
+        if world == 1 and not args.no_extras:
+            out["other_kinds"] = other_kinds(ctx, synth)
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline()

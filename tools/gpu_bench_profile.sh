@@ -7,5 +7,5 @@ make -C oracle > /dev/null
 python -m pytest tests -m gpu -x -q 2>&1 | tail -5
 python -c "import __graft_entry__ as g; g.smoke()"
 python bench.py --steps 3 --warmup 1 | tee gpurun_out/bench.json
-rocprofv3 --kernel-trace --stats -d gpurun_out/prof -o bench --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/prof/bench_prof.log 2>&1
+rocprofv3 --kernel-trace --stats -d gpurun_out/prof -o bench --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras > gpurun_out/prof/bench_prof.log 2>&1
 tail -2 gpurun_out/prof/bench_prof.log

@@ -12,9 +12,8 @@ def main():
     stats, bench = sys.argv[1], sys.argv[2]
     rows = list(csv.DictReader(open(stats)))
     line = json.loads(open(bench).read().strip().splitlines()[-1])
-    print("# rocprofv3 --kernel-trace --stats of `python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline` (1 MI355X)\n")
-    print("3 batches of 8 proofs (128 G1 scalar-muls each, 2^16 rows), the exclusive NTT re-run and the two tall\n"
-          "(2^19-row) proofs that bench.py reports beside the headline.\n")
+    print("# rocprofv3 --kernel-trace --stats of `python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras` (1 MI355X)\n")
+    print("3 batches of 8 proofs (128 G1 scalar-muls each, 2^16 rows) and the exclusive NTT re-run.\n")
     print("| kernel | calls | total ms | avg us | % |")
     print("|---|---|---|---|---|")
     for r in rows:
