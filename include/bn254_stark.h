@@ -51,7 +51,8 @@ enum {
   BN254S_E_INVALID_POINT = -4,  /* a + (-a) met during the double-and-add chain (generate_g1_add, add.rs:49-51) */
   BN254S_E_UNSUPPORTED = -5,    /* shape not implemented by this build */
   BN254S_E_TRANSCRIPT = -6,     /* opening point inside the subgroup (starky "Opening point is in the subgroup") */
-  BN254S_E_INTERNAL = -7        /* a device-side self check failed (the reference's assert!s in modulus_zero.rs:82,99-103) */
+  BN254S_E_INTERNAL = -7,       /* a device-side self check failed (the reference's assert!s in modulus_zero.rs:82,99-103) */
+  BN254S_E_VERIFY = -8          /* bn254s_verify: the proof was rejected; bn254s_last_error holds the reference's error text */
 };
 
 typedef struct bn254s_ctx bn254s_ctx;
@@ -113,6 +114,16 @@ int bn254s_proof_stage_ms(const bn254s_proof* p, const float** ms, size_t* n_sta
 const char* bn254s_stage_name(size_t stage);
 size_t bn254s_proof_serialize(const bn254s_proof* p, uint8_t* buf, size_t cap); /* LE bytes of the word layout */
 void bn254s_proof_free(bn254s_proof* p);
+
+/* Native verification of a proof in the word layout above: the reference's `verify` (src/starks/common/verifier.rs:32-98:
+ * challenges, starky's verify_stark_proof_with_challenges, plonky2's verify_fri_proof) plus the cross-table-lookup check
+ * against the claimed inputs and outputs (common/ctl_values.rs:28-47 with the rows of scalar_mul_ctl.rs:57-80 /
+ * g2 twin / exp_ctl.rs:54-75; timestamps are 0..n-1).  kind 0 = G1, 1 = G2, 2 = Fq exp (offset NULL); outputs = the
+ * n x (8 | 16 | 4) words of bn254s_proof_outputs.  Returns BN254S_OK, or BN254S_E_VERIFY with the reason in
+ * bn254s_last_error.  The constraint sum at zeta is evaluated by the quotient kernels (csrc/verify.hip), so a GPU is needed. */
+int bn254s_verify(bn254s_ctx* ctx, int kind, const bn254s_params* params, uint32_t degree_bits, const uint64_t* words,
+                  size_t n_words, const uint64_t* scalars, const uint64_t* x, const uint64_t* offset, const uint64_t* outputs,
+                  size_t n);
 
 /* ---- kernel-level entry points (parity tests and bench.py's roofline leg) ------------------------------ */
 /* PolynomialBatch::from_values on host column-major values[C][2^16]: outputs (any may be NULL)

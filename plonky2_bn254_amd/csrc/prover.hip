@@ -15,6 +15,7 @@
 #include "quotient.h"
 #include "fri.h"
 #include "transcript.h"
+#include "prover.h"
 
 // ---- shapes -------------------------------------------------------------------------------------------------
 // Stark::lookups (range-checked columns), the two looked CTL tables and the constraint counts of the three AIRs:
@@ -46,10 +47,10 @@ static StarkShape make_shape(bool input_has_a, int n_constraints) {
   return s;
 }
 StarkShape g1_shape() { return make_shape<G1L>(true, 1111); }
-static StarkShape shape_for(int kind) {
+StarkShape shape_for(int kind) {
   return kind == KIND_G1 ? make_shape<G1L>(true, 1111) : kind == KIND_G2 ? make_shape<G2L>(true, 1693) : make_shape<FQL>(false, 770);
 }
-static int point_words(int kind) { return kind == KIND_G1 ? 8 : kind == KIND_G2 ? 16 : 4; }
+int point_words(int kind) { return kind == KIND_G1 ? 8 : kind == KIND_G2 ? 16 : 4; }
 
 // ---- proof object ---------------------------------------------------------------------------------------------
 enum { ST_TRACE = 0, ST_TRACE_NTT, ST_TRACE_MERKLE, ST_AUX, ST_AUX_NTT, ST_AUX_MERKLE, ST_QUOTIENT, ST_QUOTIENT_COMMIT,
@@ -68,7 +69,7 @@ static size_t rows_for(size_t n, uint32_t min_rows_log2) {
   while (p < r) p <<= 1;
   return p;
 }
-static std::vector<int> fri_arities(const bn254s_params& P, int degree_bits) {  // ConstantArityBits(arity, final)
+std::vector<int> fri_arities(const bn254s_params& P, int degree_bits) {  // ConstantArityBits(arity, final)
   std::vector<int> a;
   int d = degree_bits;
   while (d > (int)P.final_poly_bits && d + (int)P.rate_bits - (int)P.arity_bits >= (int)P.cap_height) {

@@ -18,6 +18,10 @@ class LibraryMissing(RuntimeError):
     pass
 
 
+class VerifyError(RuntimeError):
+    """bn254s_verify rejected the proof; the message is the reference verifier's error text."""
+
+
 class Params(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in (
         "struct_size", "security_bits", "num_challenges", "rate_bits", "cap_height", "pow_bits",
@@ -56,6 +60,7 @@ def load_library():
     lib.bn254s_stage_name.argtypes = [C.c_size_t]
     lib.bn254s_stage_name.restype = C.c_char_p
     lib.bn254s_proof_free.argtypes = [vp]
+    lib.bn254s_verify.argtypes = [vp, C.c_int, C.POINTER(Params), C.c_uint32, vp, C.c_size_t, vp, vp, vp, vp, C.c_size_t]
     lib.bn254s_commit_values.argtypes = [vp, vp, C.c_size_t, vp, vp, vp]
     lib.bn254s_bench_ntt.argtypes = [vp, C.c_size_t, C.c_int, C.POINTER(C.c_float)]
     lib.bn254s_poseidon_permute.argtypes = [vp, vp, C.c_size_t]
@@ -172,6 +177,17 @@ class Context:
         self._check(self._lib.bn254s_prove_batch(self._h, kind, C.byref(params), _ptr(scalars), _ptr(x), _ptr(offset), n,
                                                  per_proof, outs), "bn254s_prove_batch")
         return [Proof(self._lib, C.c_void_p(outs[i])) for i in range(k)]
+
+    def verify(self, kind, words, degree_bits, scalars, x, offset, outputs, params: Optional[Params] = None):
+        """Native `verify` (src/starks/common/verifier.rs:32-98 + CTL check): returns None or raises VerifyError(reason)."""
+        params = params or default_params()
+        words = np.ascontiguousarray(words, dtype=np.uint64)
+        outputs = np.ascontiguousarray(outputs, dtype=np.uint64)
+        rc = self._lib.bn254s_verify(self._h, kind, C.byref(params), degree_bits, _ptr(words), words.size, _ptr(scalars), _ptr(x),
+                                     _ptr(offset), _ptr(outputs), scalars.shape[0])
+        if rc == -8:
+            raise VerifyError(self._lib.bn254s_last_error(self._h).decode())
+        self._check(rc, "bn254s_verify")
 
     # ---- kernel-level entry points ----
     def commit_values(self, values: np.ndarray, want_coeffs=True, want_lde=True):
