@@ -1,0 +1,69 @@
+"""map_to_g2 front-end (BASELINE.json configs[4]): the host arithmetic around the two STARK job kinds, and the pipeline
+fq_exp proofs -> Legendre results -> G2 cofactor-clearing proofs on the GPU (src/utils/hash_to_g2.rs:113-148,150-207)."""
+import numpy as np
+import pytest
+
+from plonky2_bn254_amd import map_to_g2 as m2g
+from plonky2_bn254_amd import synth
+
+
+def on_twist(pt):
+    return synth.f2_mul(pt[1], pt[1]) == m2g.g(pt[0])
+
+
+def test_square_roots_and_constants():
+    rng = synth.Xoshiro256ss(7)
+    n_sq = 0
+    for _ in range(40):
+        a = (rng.next_u256() % synth.P, rng.next_u256() % synth.P)
+        r = m2g.f2_sqrt(a)
+        is_sq = m2g.fq_is_square(m2g.f2_norm(a))  # a is a square in Fq2 iff its norm is a square in Fq
+        assert (r is not None) == is_sq
+        if r is not None:
+            assert synth.f2_mul(r, r) == a
+            n_sq += 1
+    assert 5 < n_sq < 35
+    assert m2g.f2_sqrt((4, 0)) in ((2, 0), (synth.P - 2, 0))
+    r = m2g.f2_sqrt((synth.P - 4, 0))  # -4 = (2u)^2
+    assert r is not None and synth.f2_mul(r, r) == (synth.P - 4, 0)
+    assert synth.f2_mul(m2g._TV4, m2g._TV4) == synth.f2_mul(m2g.f2_neg(m2g._GZ), (3, 0))
+    assert on_twist(synth.G2_GEN)
+
+
+def test_candidates_and_cofactor_clearing():
+    us = m2g.inputs(6, seed=11)
+    fs, fx = m2g.fq_exp_jobs(us)
+    assert fs.shape == (12, 4) and fx.shape == (12, 4)
+    legendre = []
+    for k in range(12):
+        assert synth.words_to_int(fs[k]) == (synth.P - 1) // 2
+        v = pow(synth.words_to_int(fx[k]), (synth.P - 1) // 2, synth.P)
+        assert v in (1, synth.P - 1)
+        legendre.append(v)
+    gs, gx, goff, pts = m2g.g2_jobs(us, legendre, seed=3)
+    for k, (pt, off) in enumerate(pts):
+        assert on_twist(pt) and on_twist(off)
+        assert m2g.sgn(pt[1]) == m2g.sgn(us[k])
+        assert synth.words_to_int(gs[k]) == m2g.COFACTOR
+        q = synth.g2_mul(m2g.COFACTOR, pt)  # cofactor * (point of the full twist group) lies in the r-torsion subgroup
+        assert on_twist(q)
+        assert synth.g2_mul(synth.R_ORDER - 1, q) == (q[0], m2g.f2_neg(q[1]))
+    # at least one input takes each of the first two branches with overwhelming probability over 6 inputs
+    assert any(legendre[2 * k] == 1 for k in range(6))
+
+
+@pytest.mark.gpu
+def test_pipeline_on_gpu(gpu_ctx):
+    us = m2g.inputs(5, seed=23)
+    fs, fx = m2g.fq_exp_jobs(us)
+    pf = gpu_ctx.prove_fq_exp(fs, fx)
+    legendre = [synth.words_to_int(w) for w in pf.outputs.reshape(-1, 4)]
+    for k in range(10):
+        assert legendre[k] == pow(synth.words_to_int(fx[k]), (synth.P - 1) // 2, synth.P)
+    gpu_ctx.verify(2, pf.words, pf.degree_bits, fs, fx, None, pf.outputs)
+    gs, gx, goff, pts = m2g.g2_jobs(us, legendre, seed=5)
+    pg = gpu_ctx.prove_g2(gs, gx, goff)
+    gpu_ctx.verify(1, pg.words, pg.degree_bits, gs, gx, goff, pg.outputs)
+    outs = pg.outputs.reshape(-1, 16)
+    for k, (pt, off) in enumerate(pts):
+        assert m2g.finish(outs[k], off) == synth.g2_mul(m2g.COFACTOR, pt)
