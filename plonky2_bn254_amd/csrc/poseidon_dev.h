@@ -12,7 +12,7 @@ static __constant__ u64 POSEIDON_RC_DEV[360] = {
 #include "poseidon_constants.inc"
 };
 // partial rounds: the constants of lanes 1..11 pushed through the linear layer (tools/derive_poseidon_constants.py)
-static __constant__ u64 POSEIDON_FOLD_DEV[22 * 24] = {
+static __constant__ u64 POSEIDON_FOLD_DEV[30 * 24] = {
 #include "poseidon_partial_fold.inc"
 };
 
@@ -62,8 +62,9 @@ GL_HD u64 poseidon_sbox(u64 x) {
 #if defined(__HIP_DEVICE_COMPILE__)
 // gfx950: every term is one v_mad_u64_u32 (32 x 32 + 64).  The constants 2, 8 and 16 are handed over in SGPRs the optimiser
 // cannot see through, otherwise it turns those products into 64-bit shifts that cost two extra moves each.
-// k != nullptr: the accumulators of output r start from k[2r], k[2r+1] (folded partial-round constants) instead of 0.
-__device__ __forceinline__ void poseidon_mds(u64 s[12], const u64* __restrict__ k = nullptr) {
+// FOLD: the accumulators of output r start from k[2r], k[2r+1] (folded constants of a partial round) instead of 0.
+template <bool FOLD>
+__device__ __forceinline__ void poseidon_mds(u64 s[12], const u64* __restrict__ k) {
   u32 c2, c8, c16;
   asm("s_mov_b32 %0, 2" : "=s"(c2));
   asm("s_mov_b32 %0, 8" : "=s"(c8));
@@ -83,8 +84,8 @@ __device__ __forceinline__ void poseidon_mds(u64 s[12], const u64* __restrict__ 
     u64 al[4], ah[4];
 #pragma unroll
     for (int q = 0; q < 4; q++) {
-      al[q] = k ? k[2 * (r0 + q)] : 0;
-      ah[q] = k ? k[2 * (r0 + q) + 1] : 0;
+      al[q] = FOLD ? k[2 * (r0 + q)] : 0;
+      ah[q] = FOLD ? k[2 * (r0 + q) + 1] : 0;
     }
 #pragma unroll
     for (int i = 0; i < 12; i++) {
@@ -137,14 +138,20 @@ inline void poseidon_mds(u64 s[12]) {
 
 GL_HD void poseidon_permute(u64 s[12]) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  for (int rnd = 0; rnd < 30; rnd++) {
-    if (rnd < 4 || rnd >= 26) {
+#pragma unroll 1
+  for (int half = 0; half < 2; half++) {
+#pragma unroll 1
+    for (int rnd = 26 * half; rnd < 26 * half + 4; rnd++) {  // 4 full rounds
 #pragma unroll
       for (int i = 0; i < 12; i++) s[i] = poseidon_sbox_lazy(gl_add_lazy(s[i], POSEIDON_RC_DEV[12 * rnd + i]));
-      poseidon_mds(s);
-    } else {
-      s[0] = poseidon_sbox_lazy(gl_add_lazy(s[0], POSEIDON_RC_DEV[12 * rnd]));
-      poseidon_mds(s, POSEIDON_FOLD_DEV + 24 * (rnd - 4));
+      poseidon_mds<false>(s, nullptr);
+    }
+    if (half == 0) {
+#pragma unroll 1
+      for (int rnd = 4; rnd < 26; rnd++) {  // 22 partial rounds
+        s[0] = poseidon_sbox_lazy(gl_add_lazy(s[0], POSEIDON_RC_DEV[12 * rnd]));
+        poseidon_mds<true>(s, POSEIDON_FOLD_DEV + 24 * rnd);
+      }
     }
   }
 #pragma unroll
