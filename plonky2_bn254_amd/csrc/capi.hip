@@ -82,13 +82,12 @@ int bn254s_commit_values(bn254s_ctx* c, const uint64_t* values, size_t ncols, ui
   HIP_TRY(c, hipSetDevice(c->device));
   const size_t N = NTT_N;
   u64* d_vals = c->words("cv.vals", ncols * N);
-  u64* d_tmp = c->words("cv.tmp", ncols * N);
+  u64* d_tmp = c->words("cv.tmp", 3 * ncols * N);
   u64* d_lde = c->words("cv.lde", ncols * 2 * N);
   u64* d_tree = c->words("cv.tree", merkle_tree_digests(17, 4) * 4);
   if (!d_vals || !d_tmp || !d_lde || !d_tree) return BN254S_E_OOM;
   HIP_TRY(c, hipMemcpyAsync(d_vals, values, ncols * N * 8, hipMemcpyHostToDevice, c->stream));
-  ntt_inverse(&c->ntt, d_vals, d_vals, d_tmp, (int)ncols, c->stream);
-  ntt_lde(&c->ntt, d_vals, d_lde, d_tmp, (int)ncols, c->stream);
+  ntt_inverse_lde(&c->ntt, d_vals, d_vals, d_lde, d_tmp, d_tmp + ncols * N, (int)ncols, c->stream);
   merkle_build(d_lde, 1, 2 * N, (int)ncols, 17, 4, d_tree, c->stream);
   HIP_TRY(c, hipGetLastError());
   if (coeffs) HIP_TRY(c, hipMemcpyAsync(coeffs, d_vals, ncols * N * 8, hipMemcpyDeviceToHost, c->stream));
@@ -114,7 +113,7 @@ int bn254s_bench_ntt(bn254s_ctx* c, size_t ncols, int iters, float* ms) {
   HIP_TRY(c, hipSetDevice(c->device));
   const size_t N = NTT_N;
   u64* d_vals = c->words("cv.vals", ncols * N);
-  u64* d_tmp = c->words("cv.tmp", ncols * N);
+  u64* d_tmp = c->words("cv.tmp", 3 * ncols * N);
   u64* d_lde = c->words("cv.lde", ncols * 2 * N);
   if (!d_vals || !d_tmp || !d_lde) return BN254S_E_OOM;
   size_t n = ncols * N;
@@ -123,13 +122,9 @@ int bn254s_bench_ntt(bn254s_ctx* c, size_t ncols, int iters, float* ms) {
   HIP_TRY(c, hipEventCreate(&e0));
   HIP_TRY(c, hipEventCreate(&e1));
   // warm-up
-  ntt_inverse(&c->ntt, d_vals, d_vals, d_tmp, (int)ncols, c->stream);
-  ntt_lde(&c->ntt, d_vals, d_lde, d_tmp, (int)ncols, c->stream);
+  ntt_inverse_lde(&c->ntt, d_vals, d_vals, d_lde, d_tmp, d_tmp + n, (int)ncols, c->stream);
   HIP_TRY(c, hipEventRecord(e0, c->stream));
-  for (int it = 0; it < iters; it++) {
-    ntt_inverse(&c->ntt, d_vals, d_vals, d_tmp, (int)ncols, c->stream);
-    ntt_lde(&c->ntt, d_vals, d_lde, d_tmp, (int)ncols, c->stream);
-  }
+  for (int it = 0; it < iters; it++) ntt_inverse_lde(&c->ntt, d_vals, d_vals, d_lde, d_tmp, d_tmp + n, (int)ncols, c->stream);
   HIP_TRY(c, hipEventRecord(e1, c->stream));
   HIP_TRY(c, hipEventSynchronize(e1));
   float t = 0;

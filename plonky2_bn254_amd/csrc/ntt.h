@@ -18,6 +18,8 @@ void ntt_tables_free(NttTables* T);
 void ntt_inverse(const NttTables* T, const u64* values, u64* coeffs, u64* tmp, int ncols, hipStream_t s);
 void ntt_coset_inverse(const NttTables* T, int h, const u64* values, u64* coeffs, u64* tmp, int ncols, hipStream_t s);
 void ntt_lde(const NttTables* T, const u64* coeffs, u64* lde, u64* tmp, int ncols, hipStream_t s);
+// from_values in one go (iNTT + both coset NTTs, middle passes fused): tmp[C][N], tmp2[2][C][N]; values == coeffs allowed
+void ntt_inverse_lde(const NttTables* T, const u64* values, u64* coeffs, u64* lde, u64* tmp, u64* tmp2, int ncols, hipStream_t s);
 void ntt_coset_forward_natural(const NttTables* T, int h, const u64* coeffs, u64* values, u64* tmp, int ncols, hipStream_t s);
 
 // ---- N = R * 2^16 (tall traces) ---------------------------------------------------------------------------------

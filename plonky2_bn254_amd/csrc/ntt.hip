@@ -169,6 +169,56 @@ __global__ __launch_bounds__(256) void k_ntt_pass2(const u64* __restrict__ in, s
   }
 }
 
+// ---- fused: pass 2 of the iNTT + pass 1 of both coset NTTs ------------------------------------------------------
+// The tile that pass 2 of the inverse transform finishes (16 rows k1 x all k2, coefficient index k1 + 256 k2) is exactly the
+// tile pass 1 of a forward transform starts from (16 adjacent columns i2 = k1 x all i1 = k2), and after the MODE-2 tile
+// the lane that owns (d, ka) holds the coefficients k2 = ka + 16 kb it needs there (a register renaming, x[br4(kb)] -> m = kb).
+// So the coefficients are stored once (they are kept for the openings) and the two coset transforms continue from registers:
+// the commitment moves 80 N bytes per column instead of 96 N and needs four launches instead of six.
+// grid = (16 tiles, ncols); y0 / y1 = pass-1 output of the cosets g and g*w_2N ([k1][i2] images for k_ntt_pass2).
+__global__ __launch_bounds__(256, 2) void k_ntt_intt2_lde1(const u64* __restrict__ in, size_t in_stride, u64* __restrict__ coef,
+                                                        size_t coef_stride, u64* __restrict__ y0, u64* __restrict__ y1,
+                                                        size_t y_stride, u64 n_inv, const u64* __restrict__ tw256_inv,
+                                                        const u64* __restrict__ pre0, const u64* __restrict__ pre1,
+                                                        const u64* __restrict__ twmat, const u64* __restrict__ tw256_fwd) {
+  __shared__ u64 lds[LDS_TILE_WORDS];
+  const int t = threadIdx.x;
+  int g = t & 15, d = t >> 4;
+  const u64* col = in + (size_t)blockIdx.y * in_stride;
+  u64 x[16], c[16];
+  {
+    const int k1_load = blockIdx.x * 16 + d;
+#pragma unroll
+    for (int m = 0; m < 16; m++) x[m] = col[k1_load * 256 + g + 16 * m];
+  }
+  dft256_tile<true, 2>(x, lds, tw256_inv, d, g);  // now d = t & 15 (row k1 of the tile), g = t >> 4 = ka
+  const int i2 = blockIdx.x * 16 + d;               // k1 of the inverse transform = matrix column i2 of the forward ones
+  u64* ocol = coef + (size_t)blockIdx.y * coef_stride;
+#pragma unroll
+  for (int kb = 0; kb < 16; kb++) {
+    c[kb] = gl_mul(x[br4(kb)], n_inv);
+    ocol[i2 + 256 * (g + 16 * kb)] = c[kb];
+  }
+#pragma unroll 1
+  for (int h = 0; h < 2; h++) {
+    const u64* __restrict__ pre = h ? pre1 : pre0;
+    u64* ycol = (h ? y1 : y0) + (size_t)blockIdx.y * y_stride;
+#pragma unroll
+    for (int m = 0; m < 16; m++) {
+      x[m] = gl_mul(c[m], pre[(g + 16 * m) * 256 + i2]);
+      if ((m & 3) == 3) asm volatile("" ::: "memory");  // at most four table loads in flight: keeps the kernel free of spills
+    }
+    __syncthreads();  // the previous tile's LDS reads are done
+    dft256_tile<false, 0>(x, lds, tw256_fwd, d, g);
+#pragma unroll
+    for (int kb = 0; kb < 16; kb++) {
+      int k1 = g + 16 * kb;
+      ycol[k1 * 256 + i2] = gl_mul(x[br4(kb)], twmat[k1 * 256 + i2]);
+      if ((kb & 3) == 3) asm volatile("" ::: "memory");
+    }
+  }
+}
+
 // ---- host side ------------------------------------------------------------------------------------------------
 static void fill_pow_table(std::vector<u64>& t, u64 base, size_t n, u64 first = 1) {
   t.resize(n);
@@ -252,6 +302,17 @@ void ntt_lde(const NttTables* T, const u64* coeffs, u64* lde, u64* tmp, int ncol
     k_ntt_pass1<false><<<grid, block, 0, s>>>(coeffs, NTT_N, tmp, NTT_N, T->coset_pow[h], T->twmat_fwd, T->tw256_fwd, 0);
     k_ntt_pass2<false, true><<<grid, block, 0, s>>>(tmp, NTT_N, lde + (size_t)h * NTT_N, 2 * NTT_N, nullptr, 1, T->tw256_fwd, 0);
   }
+}
+// values[C][N] -> coefficients[C][N] and lde[C][2N] (bit-reversed) with the fused middle kernel; tmp[C][N], tmp2[2][C][N].
+void ntt_inverse_lde(const NttTables* T, const u64* values, u64* coeffs, u64* lde, u64* tmp, u64* tmp2, int ncols, hipStream_t s) {
+  dim3 grid(16, ncols), block(256);
+  u64* y0 = tmp2;
+  u64* y1 = tmp2 + (size_t)ncols * NTT_N;
+  k_ntt_pass1<true><<<grid, block, 0, s>>>(values, NTT_N, tmp, NTT_N, nullptr, T->twmat_inv, T->tw256_inv, 0);
+  k_ntt_intt2_lde1<<<grid, block, 0, s>>>(tmp, NTT_N, coeffs, NTT_N, y0, y1, NTT_N, T->n_inv, T->tw256_inv, T->coset_pow[0],
+                                          T->coset_pow[1], T->twmat_fwd, T->tw256_fwd);
+  k_ntt_pass2<false, true><<<grid, block, 0, s>>>(y0, NTT_N, lde, 2 * NTT_N, nullptr, 1, T->tw256_fwd, 0);
+  k_ntt_pass2<false, true><<<grid, block, 0, s>>>(y1, NTT_N, lde + NTT_N, 2 * NTT_N, nullptr, 1, T->tw256_fwd, 0);
 }
 // forward coset NTT on coset h, natural output (used for small FRI-side transforms and tests)
 void ntt_coset_forward_natural(const NttTables* T, int h, const u64* coeffs, u64* values, u64* tmp, int ncols, hipStream_t s) {

@@ -182,9 +182,14 @@ static int prove_on_slot(bn254s_ctx* c, Slot& sl, int kind, const bn254s_params&
     }
   }
   // iNTT / LDE / coset iNTT dispatch: 2^16-row traces use the four-step kernels directly, taller ones add the outer pass
-  auto do_intt = [&](const u64* vals, u64* coef, int nc) {
-    if (log_r) ntt_inverse_tall(&c->ntt, TT, vals, coef, d_tmp_fwd, nc, st);
-    else ntt_inverse(&c->ntt, vals, coef, d_tmp_fwd, nc, st);
+  // from_values of a whole commitment: the fused four-launch form for 2^16 rows, iNTT then LDE otherwise
+  auto do_commit_ntt = [&](const u64* vals, u64* coef, u64* lde, int nc) {
+    if (log_r) {
+      ntt_inverse_tall(&c->ntt, TT, vals, coef, d_tmp_fwd, nc, st);
+      ntt_lde_tall(&c->ntt, TT, coef, lde, d_tmp_fwd, nc, st);
+    } else {
+      ntt_inverse_lde(&c->ntt, vals, coef, lde, d_tmp_fwd, d_tmp_fwd + (size_t)nc * N, nc, st);
+    }
   };
   auto do_lde = [&](const u64* coef, u64* lde, int nc) {
     if (log_r) ntt_lde_tall(&c->ntt, TT, coef, lde, d_tmp_fwd, nc, st);
@@ -199,7 +204,7 @@ static int prove_on_slot(bn254s_ctx* c, Slot& sl, int kind, const bn254s_params&
   u64* d_in = mem.words("in", in_words + 16);
   u64* d_tvals = mem.words("tvals", (size_t)W * N);
   u64* d_tcoef = mem.words("tcoef", (size_t)W * N);
-  u64* d_tmp = mem.words("tmp", (size_t)std::max(W, A) * N);
+  u64* d_tmp = mem.words("tmp", (size_t)(log_r ? 1 : 3) * std::max(W, A) * N);  // [tmp | y0 | y1] for the fused commitment
   d_tmp_fwd = d_tmp;
   u64* d_tlde = mem.words("tlde", (size_t)W * M2);
   const size_t tree_words = merkle_tree_digests(log_m2, P.cap_height) * 4;
@@ -292,8 +297,7 @@ static int prove_on_slot(bn254s_ctx* c, Slot& sl, int kind, const bn254s_params&
   {
     BigSection big(c, st, BIG_NTT);
     sb(ST_TRACE_NTT);
-    do_intt(d_tvals, d_tcoef, W);
-    do_lde(d_tcoef, d_tlde, W);
+    do_commit_ntt(d_tvals, d_tcoef, d_tlde, W);
     se(ST_TRACE_NTT);
   }
   {
@@ -333,8 +337,7 @@ static int prove_on_slot(bn254s_ctx* c, Slot& sl, int kind, const bn254s_params&
   {
     BigSection big(c, st, BIG_NTT);
     sb(ST_AUX_NTT);
-    do_intt(d_avals, d_acoef, A);
-    do_lde(d_acoef, d_alde, A);
+    do_commit_ntt(d_avals, d_acoef, d_alde, A);
     se(ST_AUX_NTT);
   }
   {
