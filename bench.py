@@ -157,15 +157,15 @@ def main():
     if rank == 0:
         total_proofs = world * PROOFS_PER_STEP * args.steps
         stage_ms = {k: v / max(n_acc, 1) for k, v in stage_acc.items()}
-        # roofline of the NTT/LDE stage (north-star kernel): HIP-event time of the six k_ntt_pass1/pass2
-        # launches of one commitment, measured on the proof's own stream inside the timed region.
+        # roofline of the NTT/LDE stage (north-star kernel): HIP-event time of the four NTT launches
+        # of one commitment, measured on the proof's own stream inside the timed region.
         ntt_ms = stage_ms.get("trace_ntt", 0.0) + stage_ms.get("aux_ntt", 0.0)
         ntt_bytes = NTT_BYTES_PER_COL * (W + A)
         achieved = ntt_bytes / (ntt_ms * 1e-3) / 1e9 if ntt_ms > 0 else 0.0
         # the same stage alone on the GPU (no other stream), after the timed region
         excl_ms = ctx.bench_ntt(W + A, 5)
         excl = ntt_bytes / (excl_ms * 1e-3) / 1e9
-        # HBM traffic of the same six launches from the PMC passes (FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc_ntt.md)
+        # HBM traffic of the same four launches from the PMC passes (FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc_ntt.md)
         traffic = None
         try:
             with open(os.path.join(ROOT, "profiles", "r01_pmc_ntt.json")) as f:
@@ -205,14 +205,15 @@ def main():
             "scalar_muls_per_s": round(total_proofs * INSTANCES_PER_PROOF / dt, 1),
             "stage_ms_per_proof": {k: round(v, 3) for k, v in stage_ms.items()},
             "one_tall_proof_of_1024": tall,
-            "roofline": {"bound": "hbm", "kernel": "ntt_lde stage = k_ntt_pass1 + k_ntt_pass2 x {iNTT, coset g, coset g*w_2N} "
-                                                   "over the 781 trace + 456 aux columns of one proof",
+            "roofline": {"bound": "hbm", "kernel": "ntt_lde stage = k_ntt_pass1 (iNTT) + k_ntt_intt2_lde1 (fused iNTT pass 2 / pass 1 of "
+                                                   "both cosets) + k_ntt_pass2 x {coset g, coset g*w_2N} over the 781 trace + 456 aux "
+                                                   "columns of one proof",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "algorithmic_bytes": ntt_bytes, "ms": round(ntt_ms, 4),
                          "exclusive": {"achieved": round(excl, 1), "frac": round(excl / HBM_PEAK_GBS, 4),
                                        "ms": round(excl_ms, 4),
-                                       "note": "same six launches with no other stream on the GPU (bn254s_bench_ntt)"}},
+                                       "note": "same four launches with no other stream on the GPU (bn254s_bench_ntt)"}},
         }
         if world == 1 and not args.no_extras:
             out["other_kinds"] = other_kinds(ctx, synth)
