@@ -38,4 +38,6 @@ void ntt_inverse_tall(const NttTables* T, const NttTallTables* TT, const u64* va
                       hipStream_t s);
 void ntt_coset_inverse_tall(const NttTables* T, const NttTallTables* TT, int h, const u64* values, u64* coeffs, u64* tmp, int ncols,
                             hipStream_t s);
+void ntt_inverse_lde_tall(const NttTables* T, const NttTallTables* TT, const u64* values, u64* coeffs, u64* lde, u64* tmp, int ncols,
+                          hipStream_t s);
 void ntt_lde_tall(const NttTables* T, const NttTallTables* TT, const u64* coeffs, u64* lde, u64* tmp, int ncols, hipStream_t s);

@@ -180,11 +180,12 @@ __global__ __launch_bounds__(256, 2) void k_ntt_intt2_lde1(const u64* __restrict
                                                         size_t coef_stride, u64* __restrict__ y0, u64* __restrict__ y1,
                                                         size_t y_stride, u64 n_inv, const u64* __restrict__ tw256_inv,
                                                         const u64* __restrict__ pre0, const u64* __restrict__ pre1,
-                                                        const u64* __restrict__ twmat, const u64* __restrict__ tw256_fwd) {
+                                                        const u64* __restrict__ twmat, const u64* __restrict__ tw256_fwd,
+                                                        unsigned log_r) {
   __shared__ u64 lds[LDS_TILE_WORDS];
   const int t = threadIdx.x;
   int g = t & 15, d = t >> 4;
-  const u64* col = in + (size_t)blockIdx.y * in_stride;
+  const u64* col = in + col_offset(blockIdx.y, log_r, in_stride);
   u64 x[16], c[16];
   {
     const int k1_load = blockIdx.x * 16 + d;
@@ -193,7 +194,7 @@ __global__ __launch_bounds__(256, 2) void k_ntt_intt2_lde1(const u64* __restrict
   }
   dft256_tile<true, 2>(x, lds, tw256_inv, d, g);  // now d = t & 15 (row k1 of the tile), g = t >> 4 = ka
   const int i2 = blockIdx.x * 16 + d;               // k1 of the inverse transform = matrix column i2 of the forward ones
-  u64* ocol = coef + (size_t)blockIdx.y * coef_stride;
+  u64* ocol = coef + col_offset(blockIdx.y, log_r, coef_stride);
 #pragma unroll
   for (int kb = 0; kb < 16; kb++) {
     c[kb] = gl_mul(x[br4(kb)], n_inv);
@@ -202,7 +203,7 @@ __global__ __launch_bounds__(256, 2) void k_ntt_intt2_lde1(const u64* __restrict
 #pragma unroll 1
   for (int h = 0; h < 2; h++) {
     const u64* __restrict__ pre = h ? pre1 : pre0;
-    u64* ycol = (h ? y1 : y0) + (size_t)blockIdx.y * y_stride;
+    u64* ycol = (h ? y1 : y0) + col_offset(blockIdx.y, log_r, y_stride);
 #pragma unroll
     for (int m = 0; m < 16; m++) {
       x[m] = gl_mul(c[m], pre[(g + 16 * m) * 256 + i2]);
@@ -310,7 +311,7 @@ void ntt_inverse_lde(const NttTables* T, const u64* values, u64* coeffs, u64* ld
   u64* y1 = tmp2 + (size_t)ncols * NTT_N;
   k_ntt_pass1<true><<<grid, block, 0, s>>>(values, NTT_N, tmp, NTT_N, nullptr, T->twmat_inv, T->tw256_inv, 0);
   k_ntt_intt2_lde1<<<grid, block, 0, s>>>(tmp, NTT_N, coeffs, NTT_N, y0, y1, NTT_N, T->n_inv, T->tw256_inv, T->coset_pow[0],
-                                          T->coset_pow[1], T->twmat_fwd, T->tw256_fwd);
+                                          T->coset_pow[1], T->twmat_fwd, T->tw256_fwd, 0);
   k_ntt_pass2<false, true><<<grid, block, 0, s>>>(y0, NTT_N, lde, 2 * NTT_N, nullptr, 1, T->tw256_fwd, 0);
   k_ntt_pass2<false, true><<<grid, block, 0, s>>>(y1, NTT_N, lde + NTT_N, 2 * NTT_N, nullptr, 1, T->tw256_fwd, 0);
 }
@@ -503,6 +504,33 @@ void ntt_coset_inverse_tall(const NttTables* T, const NttTallTables* TT, int h, 
   ntt_inverse_tall(T, TT, values, coeffs, tmp, ncols, s);
   const size_t N = (size_t)1 << TT->log_n;
   k_coset_unscale<<<dim3((unsigned)(N / 256), ncols), 256, 0, s>>>(coeffs, N, TT->log_n - 16, gl_inv(TT->shift[h]));
+}
+// from_values of a tall commitment: outer inverse pass, block iNTT pass 1, the fused middle kernel (its two pass-1 images go
+// straight into the two halves of the LDE buffer), then pass 2 + outer forward pass per coset.  values == coeffs allowed.
+void ntt_inverse_lde_tall(const NttTables* T, const NttTallTables* TT, const u64* values, u64* coeffs, u64* lde, u64* tmp, int ncols,
+                          hipStream_t s) {
+  const unsigned log_r = TT->log_n - 16;
+  const size_t N = (size_t)1 << TT->log_n;
+  switch (log_r) {
+    case 1: outer_inv_launch<1>(values, coeffs, N, TT, ncols, s); break;
+    case 2: outer_inv_launch<2>(values, coeffs, N, TT, ncols, s); break;
+    case 3: outer_inv_launch<3>(values, coeffs, N, TT, ncols, s); break;
+    default: outer_inv_launch<4>(values, coeffs, N, TT, ncols, s); break;
+  }
+  dim3 grid(16, (unsigned)(ncols << log_r)), block(256);
+  k_ntt_pass1<true><<<grid, block, 0, s>>>(coeffs, N, tmp, N, nullptr, T->twmat_inv, T->tw256_inv, log_r);
+  k_ntt_intt2_lde1<<<grid, block, 0, s>>>(tmp, N, coeffs, N, lde, lde + N, 2 * N, T->n_inv, T->tw256_inv, TT->block_coset_pow[0],
+                                          TT->block_coset_pow[1], T->twmat_fwd, T->tw256_fwd, log_r);
+  for (int h = 0; h < 2; h++) {
+    u64* half = lde + (size_t)h * N;
+    k_ntt_pass2<false, true><<<grid, block, 0, s>>>(half, 2 * N, tmp, N, nullptr, 1, T->tw256_fwd, log_r);
+    switch (log_r) {
+      case 1: outer_fwd_launch<1>(tmp, N, half, 2 * N, TT, h, ncols, s); break;
+      case 2: outer_fwd_launch<2>(tmp, N, half, 2 * N, TT, h, ncols, s); break;
+      case 3: outer_fwd_launch<3>(tmp, N, half, 2 * N, TT, h, ncols, s); break;
+      default: outer_fwd_launch<4>(tmp, N, half, 2 * N, TT, h, ncols, s); break;
+    }
+  }
 }
 // transposed coefficients[C][N] -> lde[C][2N] bit-reversed; tmp[C][N].
 void ntt_lde_tall(const NttTables* T, const NttTallTables* TT, const u64* coeffs, u64* lde, u64* tmp, int ncols, hipStream_t s) {

@@ -185,8 +185,7 @@ static int prove_on_slot(bn254s_ctx* c, Slot& sl, int kind, const bn254s_params&
   // from_values of a whole commitment: the fused four-launch form for 2^16 rows, iNTT then LDE otherwise
   auto do_commit_ntt = [&](const u64* vals, u64* coef, u64* lde, int nc) {
     if (log_r) {
-      ntt_inverse_tall(&c->ntt, TT, vals, coef, d_tmp_fwd, nc, st);
-      ntt_lde_tall(&c->ntt, TT, coef, lde, d_tmp_fwd, nc, st);
+      ntt_inverse_lde_tall(&c->ntt, TT, vals, coef, lde, d_tmp_fwd, nc, st);
     } else {
       ntt_inverse_lde(&c->ntt, vals, coef, lde, d_tmp_fwd, d_tmp_fwd + (size_t)nc * N, nc, st);
     }
