@@ -1,0 +1,92 @@
+"""Behaviour of the library around the happy path: errors leave the context usable, independent contexts may prove
+concurrently from different host threads (the threading contract of include/bn254_stark.h), the doubling /
+infinity cases of the parallel running-sum scan (csrc/chain_scan.h) agree with the sequential walk of the reference
+(src/starks/curves/g1/scalar_mul_stark.rs:92-213) as restated by the oracle."""
+import threading
+
+import numpy as np
+import pytest
+
+import plonky2_bn254_amd as pk
+from plonky2_bn254_amd import synth
+from tests import oracle_lib
+
+pytestmark = pytest.mark.gpu
+
+
+def neg_point_words(pt_words):
+    y = synth.words_to_int(pt_words[4:])
+    return list(pt_words[:4]) + [((synth.P - y) >> (64 * i)) & synth.MASK64 for i in range(4)]
+
+
+def test_context_survives_an_invalid_point(gpu_ctx):
+    s, x, o = synth.g1_inputs(4, seed=31)
+    good = gpu_ctx.prove_g1(s, x, o).words.copy()
+    bad_o = o.copy()
+    bad_o[2] = neg_point_words(x[2])  # offset = -x: the very first addition meets the point at infinity
+    with pytest.raises(RuntimeError, match="-4"):
+        gpu_ctx.prove_g1(s, x, bad_o)
+    with pytest.raises(RuntimeError, match="-4"):
+        gpu_ctx.prove_g1_batch(np.tile(s, (40, 1)), np.tile(x, (40, 1)), np.tile(bad_o, (40, 1)))
+    again = gpu_ctx.prove_g1(s, x, o)
+    assert np.array_equal(again.words, good)
+    gpu_ctx.verify(0, again.words, again.degree_bits, s, x, o, again.outputs)
+
+
+def test_running_sum_meets_infinity_later_in_the_walk(gpu_ctx, oracle):
+    """offset = -3x, bit 0 set: S_1 = -2x, so C_1 = S_1 + D_1 is the point at infinity at step 1 (whatever bit 1 is: the
+    add row is generated either way): both the sequential walk and the scan must report it."""
+    s, x, o = synth.g1_inputs(2, seed=77)
+    xp = (synth.words_to_int(x[0, :4]), synth.words_to_int(x[0, 4:]))
+    three_x = synth.g1_mul(3, xp)
+    o[0] = synth._to_words(three_x[0]) + synth._to_words(synth.P - three_x[1])
+    s[0] = [3, 0, 0, 0]
+    with pytest.raises(RuntimeError, match="-4"):
+        gpu_ctx.g1_generate_trace(s, x, o, min_rows_log2=16)
+    with pytest.raises(RuntimeError):
+        oracle_lib.generate_trace(oracle, 0, s, x, o)
+    # with bit 0 cleared S stays at -3x and never meets -D_k: fine for both, and cell-for-cell equal
+    s[0] = [0xFFFFFFFFFFFFFFFE, 5, 0, 1 << 63]
+    got, got_out = gpu_ctx.g1_generate_trace(s, x, o, min_rows_log2=16)
+    ref, ref_out = oracle_lib.generate_trace(oracle, 0, s, x, o)
+    assert np.array_equal(got, ref) and np.array_equal(got_out.reshape(ref_out.shape), ref_out)
+
+
+def test_scan_doubling_and_cancellation_cases(gpu_ctx, oracle):
+    """Partial sums of the scan that double (x added to x) or cancel (a block of bits summing to a multiple of the group
+    order) never occur in the sequential walk; the complete addition law must make them invisible in the trace."""
+    s, x, o = synth.g1_inputs(6, seed=123)
+    r = synth.R_ORDER
+    s[0] = synth._to_words(r)             # s*x = infinity: result = offset, partial sums cancel on the way
+    s[1] = synth._to_words(r + 1)
+    s[2] = synth._to_words(2 * r)
+    s[3] = synth._to_words((1 << 256) - 1)
+    s[4] = synth._to_words(0)
+    o[5] = x[5]                           # offset == x: the first addition is a doubling
+    s[5] = synth._to_words(5)
+    got, got_out = gpu_ctx.g1_generate_trace(s, x, o, min_rows_log2=16)
+    ref, ref_out = oracle_lib.generate_trace(oracle, 0, s, x, o)
+    bad = np.argwhere(got != ref)
+    assert bad.size == 0, bad[:5].tolist()
+    assert np.array_equal(got_out.reshape(ref_out.shape), ref_out)
+    for k in (0, 2, 4):
+        assert np.array_equal(got_out.reshape(-1, 8)[k], o[k])
+
+
+def test_two_contexts_prove_concurrently():
+    s, x, o = synth.g1_inputs(128 * 3, seed=9)
+    res = {}
+
+    def work(tag):
+        ctx = pk.Context(0)
+        res[tag] = [p.words.copy() for p in ctx.prove_g1_batch(s, x, o)]
+        ctx.close()
+
+    th = [threading.Thread(target=work, args=(t,)) for t in ("a", "b")]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert len(res["a"]) == 3 and len(res["b"]) == 3
+    for pa, pb in zip(res["a"], res["b"]):
+        assert np.array_equal(pa, pb)
