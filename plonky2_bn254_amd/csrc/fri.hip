@@ -19,32 +19,50 @@
 // Coefficient layout: coefficient k1 + R*k2 at position k1*M + k2 (R = N / 2^16 blocks of M = 2^16; R = 1 is the
 // plain natural order).  P(z) = sum_k1 z^k1 * sum_k2 c[k1][k2] (z^R)^k2: one 256-thread block per (polynomial, k1)
 // evaluates the inner sum at zeta^R and (g zeta)^R; the host combines the R partial values.
+// Inside a block lane t owns the coefficients t + 256 q: S(z) = sum_t z^t * sum_q c[t + 256 q] (z^256)^q.  The powers
+// (z^256)^q are the same for every lane and every polynomial, so they come from a 256-entry table through scalar loads and
+// a coefficient costs four base-field multiply-accumulates into un-reduced 128+32-bit sums (no extension-field Horner).
 // out[(p*R + k1)*5 ..] = {S0.c0, S0.c1, S1.c0, S1.c1, sum of the block's coefficients}
-__global__ __launch_bounds__(256) void k_openings(const u64* __restrict__ coeffs, size_t N, unsigned log_r, gl2 z0r, gl2 z1r,
-                                                  u64* __restrict__ out) {
+static constexpr int OPEN_Q = (int)(65536 / 256);
+
+// zq[(pt*OPEN_Q + q)*2 ..] = ((z_pt^R)^256)^q, zt[(pt*256 + t)*2 ..] = (z_pt^R)^t
+__global__ __launch_bounds__(256) void k_opening_tables(gl2 z0r, gl2 z1r, u64* __restrict__ zq, u64* __restrict__ zt) {
+  const int t = threadIdx.x;
+  for (int pt = 0; pt < 2; pt++) {
+    const gl2 z = pt ? z1r : z0r;
+    gl2 a = gl2_pow(gl2_pow(z, 256), (u64)t), b = gl2_pow(z, (u64)t);
+    zq[(pt * OPEN_Q + t) * 2] = a.c0;
+    zq[(pt * OPEN_Q + t) * 2 + 1] = a.c1;
+    zt[(pt * 256 + t) * 2] = b.c0;
+    zt[(pt * 256 + t) * 2 + 1] = b.c1;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_openings(const u64* __restrict__ coeffs, size_t N, unsigned log_r, const u64* __restrict__ zq,
+                                                  const u64* __restrict__ zt, u64* __restrict__ out) {
   __shared__ u64 red[256 * 5];
   const int t = threadIdx.x;
-  const size_t M = N >> log_r;
+  const size_t M = N >> log_r;  // = 65536
   const u64* c = coeffs + (size_t)blockIdx.x * N + (size_t)blockIdx.y * M;
-  // S(z) = sum_t z^t * sum_q c[t + 256 q] (z^256)^q
-  const gl2 z0p = gl2_pow(z0r, 256), z1p = gl2_pow(z1r, 256);
-  gl2 a0 = gl2_make(0, 0), a1 = gl2_make(0, 0);
-  u64 s = 0;
-  for (long q = (long)(M / 256) - 1; q >= 0; q--) {
-    u64 v = c[(size_t)t + 256 * (size_t)q];
-    a0 = gl2_mul(a0, z0p);
-    a0.c0 = gl_add(a0.c0, v);
-    a1 = gl2_mul(a1, z1p);
-    a1.c0 = gl_add(a1.c0, v);
-    s = gl_add(s, v);
+  Acc2 a0, a1;
+  acc2_init(a0);
+  acc2_init(a1);
+  u64 s_lo = 0, s_hi = 0;
+#pragma unroll 4
+  for (int q = 0; q < OPEN_Q; q++) {
+    const u64 v = c[(size_t)t + 256 * (size_t)q];
+    acc2_mad(a0, v, zq[2 * q], zq[2 * q + 1]);
+    acc2_mad(a1, v, zq[2 * (OPEN_Q + q)], zq[2 * (OPEN_Q + q) + 1]);
+    s_lo += v;
+    s_hi += s_lo < v ? 1 : 0;
   }
-  a0 = gl2_mul(a0, gl2_pow(z0r, (u64)t));
-  a1 = gl2_mul(a1, gl2_pow(z1r, (u64)t));
-  red[t] = a0.c0;
-  red[256 + t] = a0.c1;
-  red[512 + t] = a1.c0;
-  red[768 + t] = a1.c1;
-  red[1024 + t] = s;
+  gl2 r0 = gl2_mul(gl2_make(acc_red(a0.a0), acc_red(a0.a1)), gl2_make(zt[2 * t], zt[2 * t + 1]));
+  gl2 r1 = gl2_mul(gl2_make(acc_red(a1.a0), acc_red(a1.a1)), gl2_make(zt[2 * (256 + t)], zt[2 * (256 + t) + 1]));
+  red[t] = r0.c0;
+  red[256 + t] = r0.c1;
+  red[512 + t] = r1.c0;
+  red[768 + t] = r1.c1;
+  red[1024 + t] = gl_reduce128(s_lo, s_hi);
   __syncthreads();
   for (int off = 128; off > 0; off >>= 1) {
     if (t < off)
@@ -54,9 +72,13 @@ __global__ __launch_bounds__(256) void k_openings(const u64* __restrict__ coeffs
   if (t < 5) out[((size_t)blockIdx.x * gridDim.y + blockIdx.y) * 5 + t] = red[t * 256];
 }
 
-void fri_openings(const u64* d_coeffs, size_t N, unsigned log_r, int npolys, gl2 zeta, gl2 zeta_next, u64* d_out, hipStream_t st) {
+void fri_opening_tables(unsigned log_r, gl2 zeta, gl2 zeta_next, u64* d_tables, hipStream_t st) {
   const u64 R = (u64)1 << log_r;
-  k_openings<<<dim3(npolys, (unsigned)R), 256, 0, st>>>(d_coeffs, N, log_r, gl2_pow(zeta, R), gl2_pow(zeta_next, R), d_out);
+  k_opening_tables<<<1, 256, 0, st>>>(gl2_pow(zeta, R), gl2_pow(zeta_next, R), d_tables, d_tables + FRI_OPENING_ZQ_WORDS);
+}
+void fri_openings(const u64* d_coeffs, size_t N, unsigned log_r, int npolys, const u64* d_tables, u64* d_out, hipStream_t st) {
+  const u64 R = (u64)1 << log_r;
+  k_openings<<<dim3(npolys, (unsigned)R), 256, 0, st>>>(d_coeffs, N, log_r, d_tables, d_tables + FRI_OPENING_ZQ_WORDS, d_out);
 }
 
 // ---- batched quotient on the LDE domain ---------------------------------------------------------------

@@ -215,7 +215,7 @@ static int prove_on_slot(bn254s_ctx* c, Slot& sl, int kind, const bn254s_params&
   u64* d_scr = mem.words("scratch", std::max(trace_scr, aux_scratch_words(sh, N)));
   u64* d_q = mem.words("quot", (size_t)(3 * NQ) * N + (size_t)NQ * M2 + (size_t)QUOTIENT_MAX_PARTS * 2 * M2);  // qv, ab, qcoef, qlde, partials
   u64* d_tabs = mem.words("tabs", 2 * (size_t)K + 10 * 2 * 80 + 2 * (size_t)(W + A + NQ));
-  u64* d_open = mem.words("open", std::max((size_t)(W + A + NQ) * R * 5, n * (size_t)PW));
+  u64* d_open = mem.words("open", std::max((size_t)(W + A + NQ) * R * 5 + FRI_OPENING_TABLE_WORDS, n * (size_t)PW));
   // FRI layer values (extension, 2 words) and trees
   size_t fri_words = 0, fri_tree_words = 0;
   {
@@ -406,9 +406,11 @@ static int prove_on_slot(bn254s_ctx* c, Slot& sl, int kind, const bn254s_params&
   {
     BigSection big(c, st, BIG_EXCL);
     sb(ST_OPENINGS);
-    fri_openings(d_tcoef, N, log_r, W, zeta, zeta_next, d_open, st);
-    fri_openings(d_acoef, N, log_r, A, zeta, zeta_next, d_open + (size_t)W * R * 5, st);
-    fri_openings(d_qcoef, N, log_r, NQ, zeta, zeta_next, d_open + (size_t)(W + A) * R * 5, st);
+    u64* d_otab = d_open + (size_t)(W + A + NQ) * R * 5;
+    fri_opening_tables(log_r, zeta, zeta_next, d_otab, st);
+    fri_openings(d_tcoef, N, log_r, W, d_otab, d_open, st);
+    fri_openings(d_acoef, N, log_r, A, d_otab, d_open + (size_t)W * R * 5, st);
+    fri_openings(d_qcoef, N, log_r, NQ, d_otab, d_open + (size_t)(W + A) * R * 5, st);
   }
   std::vector<u64> h_part((size_t)(W + A + NQ) * R * 5), h_open((size_t)(W + A + NQ) * 5);
   CHK(hipMemcpyAsync(h_part.data(), d_open, h_part.size() * 8, hipMemcpyDeviceToHost, st));
