@@ -20,7 +20,8 @@ __device__ __forceinline__ void acc_init(Acc& a) {
   a.ov = 0;
 }
 __device__ __forceinline__ void acc_mad(Acc& a, u64 x, u64 w) {
-  u64 pl = x * w, ph = __umul64hi(x, w);
+  const unsigned __int128 pr = (unsigned __int128)x * w;  // one 128-bit product (shared partial products)
+  u64 pl = (u64)pr, ph = (u64)(pr >> 64);
   a.lo += pl;
   u64 c = a.lo < pl ? 1 : 0;
   u64 h = a.hi + ph;
