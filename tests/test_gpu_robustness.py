@@ -90,3 +90,12 @@ def test_two_contexts_prove_concurrently():
     assert len(res["a"]) == 3 and len(res["b"]) == 3
     for pa, pb in zip(res["a"], res["b"]):
         assert np.array_equal(pa, pb)
+
+
+def test_plain_c_host_program(tmp_path):
+    """examples/prove_g1.c: prove + verify + reject a corrupted proof through the C ABI alone."""
+    import subprocess
+    from tests.test_host_and_abi import build_c_example
+    r = subprocess.run([build_c_example(tmp_path)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "bn254s_verify: 0" in r.stdout and "corrupted proof: -8" in r.stdout

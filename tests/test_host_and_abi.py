@@ -60,3 +60,24 @@ def test_oracle_proof_length_formula(oracle):
     per_q = (W + A + 4) + 3 * 13 * 4 + (32 + 9 * 4) + (32 + 5 * 4) + (32 + 1 * 4)
     want = 3 * 64 + 2 * (2 * W + 2 * A) + 4 + 8 + 3 * 64 + 84 * per_q + 32 + 1 + 12
     assert oracle.orc_g1_proof_len(16) == want
+
+
+def build_c_example(tmp_path):
+    """examples/prove_g1.c with gcc -std=c99: the header is plain C and every entry point links without C++ or Python."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "prove_g1")
+    libdir = os.path.join(root, "plonky2_bn254_amd")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I" + os.path.join(root, "include"),
+                    os.path.join(root, "examples", "prove_g1.c"), "-L" + libdir, "-lbn254stark", "-Wl,-rpath," + libdir, "-o", exe],
+                   check=True)
+    return exe
+
+
+def test_c_example_builds_against_the_abi(tmp_path):
+    import subprocess
+    exe = build_c_example(tmp_path)
+    import torch
+    if not torch.cuda.is_available():
+        r = subprocess.run([exe], capture_output=True, text=True)
+        assert r.returncode == 2 and "bn254s_ctx_create" in r.stderr  # fails loudly without a GPU, no fallback
