@@ -125,6 +125,13 @@ int bn254s_verify(bn254s_ctx* ctx, int kind, const bn254s_params* params, uint32
                   size_t n_words, const uint64_t* scalars, const uint64_t* x, const uint64_t* offset, const uint64_t* outputs,
                   size_t n);
 
+/* The extra looking values of the two cross-table lookups (reference g1_generate_ctl_values, scalar_mul_ctl.rs:57-80; G2 twin;
+ * fq_generate_ctl_values, exp_ctl.rs:54-75), i.e. what run_once hands to set_ctl_values_target (stark_proof.rs:174-178):
+ * per instance one input row  [x limbs | offset limbs (not for Fq) | 16 scalar limbs | timestamp]  of 81 / 145 / 33 words and
+ * one output row [output limbs | timestamp] of 33 / 65 / 17 words, all 16-bit little-endian limbs.  Host only, no context. */
+int bn254s_ctl_values(int kind, const uint64_t* scalars, const uint64_t* x, const uint64_t* offset, const uint64_t* outputs,
+                      size_t n, uint64_t* in_rows, uint64_t* out_rows);
+
 /* ---- kernel-level entry points (parity tests and bench.py's roofline leg) ------------------------------ */
 /* PolynomialBatch::from_values on host column-major values[C][2^16]: outputs (any may be NULL)
  * coeffs[C][N], lde[C][2N] in Merkle-leaf (bit-reversed) order, cap[16*4]. */

@@ -445,6 +445,19 @@ int verify_impl(bn254s_ctx* c, int kind, const bn254s_params& P, int degree_bits
 
 }  // namespace
 
+extern "C" int bn254s_ctl_values(int kind, const uint64_t* scalars, const uint64_t* x, const uint64_t* off, const uint64_t* outputs,
+                                 size_t n, uint64_t* in_rows, uint64_t* out_rows) {
+  if (kind < 0 || kind > 2 || !scalars || !x || (kind != KIND_FQ && !off) || !outputs || !in_rows || !out_rows)
+    return BN254S_E_INVALID_ARG;
+  std::vector<u64> in, out;
+  for (size_t k = 0; k < n; k++) {
+    ctl_rows(kind, scalars, x, off, outputs, k, in, out);
+    memcpy(in_rows + k * in.size(), in.data(), in.size() * 8);
+    memcpy(out_rows + k * out.size(), out.data(), out.size() * 8);
+  }
+  return BN254S_OK;
+}
+
 extern "C" int bn254s_verify(bn254s_ctx* c, int kind, const bn254s_params* params, uint32_t degree_bits, const uint64_t* words,
                              size_t n_words, const uint64_t* scalars, const uint64_t* x, const uint64_t* off, const uint64_t* outputs,
                              size_t n) {

@@ -61,6 +61,7 @@ def load_library():
     lib.bn254s_stage_name.restype = C.c_char_p
     lib.bn254s_proof_free.argtypes = [vp]
     lib.bn254s_verify.argtypes = [vp, C.c_int, C.POINTER(Params), C.c_uint32, vp, C.c_size_t, vp, vp, vp, vp, C.c_size_t]
+    lib.bn254s_ctl_values.argtypes = [C.c_int, vp, vp, vp, vp, C.c_size_t, vp, vp]
     lib.bn254s_commit_values.argtypes = [vp, vp, C.c_size_t, vp, vp, vp]
     lib.bn254s_bench_ntt.argtypes = [vp, C.c_size_t, C.c_int, C.POINTER(C.c_float)]
     lib.bn254s_poseidon_permute.argtypes = [vp, vp, C.c_size_t]
@@ -188,6 +189,17 @@ class Context:
         if rc == -8:
             raise VerifyError(self._lib.bn254s_last_error(self._h).decode())
         self._check(rc, "bn254s_verify")
+
+    def ctl_values(self, kind, scalars, x, offset, outputs):
+        """(input rows [n, 81|145|33], output rows [n, 33|65|17]): the extra looking values of the two CTLs."""
+        n = scalars.shape[0]
+        pl = {0: 32, 1: 64, 2: 16}[kind]
+        rows_in = np.zeros((n, (pl if kind == 2 else 2 * pl) + 17), np.uint64)
+        rows_out = np.zeros((n, pl + 1), np.uint64)
+        outputs = np.ascontiguousarray(outputs, dtype=np.uint64)
+        self._check(self._lib.bn254s_ctl_values(kind, _ptr(scalars), _ptr(x), _ptr(offset), _ptr(outputs), n, _ptr(rows_in),
+                                                _ptr(rows_out)), "bn254s_ctl_values")
+        return rows_in, rows_out
 
     # ---- kernel-level entry points ----
     def commit_values(self, values: np.ndarray, want_coeffs=True, want_lde=True):

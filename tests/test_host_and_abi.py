@@ -81,3 +81,28 @@ def test_c_example_builds_against_the_abi(tmp_path):
     if not torch.cuda.is_available():
         r = subprocess.run([exe], capture_output=True, text=True)
         assert r.returncode == 2 and "bn254s_ctx_create" in r.stderr  # fails loudly without a GPU, no fallback
+
+
+def test_ctl_values_rows_without_gpu():
+    """bn254s_ctl_values is host-only: rows = 16-bit limbs of x | offset | scalar | timestamp and of the output | timestamp
+    (scalar_mul_ctl.rs:57-80), checked against Python integers for G1 and the Fq-exp shape."""
+    from plonky2_bn254_amd import lib as L
+    lib = L.load_library()
+
+    def limbs(words):
+        v = synth.words_to_int(words)
+        return [(v >> (16 * i)) & 0xFFFF for i in range(16)]
+
+    s, x, o = synth.g1_inputs(3, seed=4)
+    outs = np.arange(24, dtype=np.uint64).reshape(3, 8) * np.uint64(0x0123456789ABCDEF)
+    ri, ro = np.zeros((3, 81), np.uint64), np.zeros((3, 33), np.uint64)
+    assert lib.bn254s_ctl_values(0, L._ptr(s), L._ptr(x), L._ptr(o), L._ptr(outs), 3, L._ptr(ri), L._ptr(ro)) == 0
+    for k in range(3):
+        assert ri[k].tolist() == limbs(x[k, :4]) + limbs(x[k, 4:]) + limbs(o[k, :4]) + limbs(o[k, 4:]) + limbs(s[k]) + [k]
+        assert ro[k].tolist() == limbs(outs[k, :4]) + limbs(outs[k, 4:]) + [k]
+    fs, fx = synth.fq_inputs(2)
+    fo = np.ones((2, 4), np.uint64)
+    ri, ro = np.zeros((2, 33), np.uint64), np.zeros((2, 17), np.uint64)
+    assert lib.bn254s_ctl_values(2, L._ptr(fs), L._ptr(fx), None, L._ptr(fo), 2, L._ptr(ri), L._ptr(ro)) == 0
+    assert ri[1].tolist() == limbs(fx[1]) + limbs(fs[1]) + [1] and ro[1].tolist() == [1] + [0] * 15 + [1]
+    assert lib.bn254s_ctl_values(0, L._ptr(s), L._ptr(x), None, L._ptr(outs), 3, L._ptr(ri), L._ptr(ro)) == -1
