@@ -101,7 +101,8 @@ def test_ctl_values_rows_without_gpu():
         assert ri[k].tolist() == limbs(x[k, :4]) + limbs(x[k, 4:]) + limbs(o[k, :4]) + limbs(o[k, 4:]) + limbs(s[k]) + [k]
         assert ro[k].tolist() == limbs(outs[k, :4]) + limbs(outs[k, 4:]) + [k]
     fs, fx = synth.fq_inputs(2)
-    fo = np.ones((2, 4), np.uint64)
+    fo = np.zeros((2, 4), np.uint64)
+    fo[:, 0] = 1
     ri, ro = np.zeros((2, 33), np.uint64), np.zeros((2, 17), np.uint64)
     assert lib.bn254s_ctl_values(2, L._ptr(fs), L._ptr(fx), None, L._ptr(fo), 2, L._ptr(ri), L._ptr(ro)) == 0
     assert ri[1].tolist() == limbs(fx[1]) + limbs(fs[1]) + [1] and ro[1].tolist() == [1] + [0] * 15 + [1]
