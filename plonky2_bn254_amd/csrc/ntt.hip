@@ -323,34 +323,82 @@ void ntt_coset_forward_natural(const NttTables* T, int h, const u64* coeffs, u64
 }
 
 
-// ---- traces taller than 2^16 rows: N = R * 2^16, R = 2^log_r <= 16 -----------------------------------------------
+// ---- traces taller than 2^16 rows: N = R * 2^16, R = 2^log_r <= 64 -----------------------------------------------
 // An N-point transform is an R-point DFT across the R blocks of a column (shift-only twiddles, one lane per
 // in-block position, all accesses contiguous across lanes) combined with the 2^16-point kernels above on each block.
 //   inverse (values natural -> coefficients):  outer DIF pass first, then the block iNTTs.  Coefficient k1 + R*k2 ends
 //   up at [block k1][k2] ("transposed" coefficient layout; every consumer below and in fri.hip knows it).
 //   forward coset LDE (transposed coefficients -> bit-reversed values): block NTTs first (coset (shift^R)), then the
 //   outer DIT pass with twiddle (shift * w_N^k2)^i1; output position bitrev(k2)*R + bitrev_r(k1) = p*R + register index.
-__device__ __forceinline__ u64 mul_2exp12(u64 x, int e) {  // x * 2^(12 e), e in [0,16); e is a compile-time constant after unrolling
+__device__ __forceinline__ u64 mul_2exp3(u64 x, int e) {  // x * 2^(3 e) = x * w_64^e, e in [0,64); e is a compile-time constant after unrolling
   switch (e) {
     case 0: return x;
-    case 1: return gl_mul_2exp<12>(x);
-    case 2: return gl_mul_2exp<24>(x);
-    case 3: return gl_mul_2exp<36>(x);
-    case 4: return gl_mul_2exp<48>(x);
-    case 5: return gl_mul_2exp<60>(x);
-    case 6: return gl_mul_2exp<72>(x);
-    case 7: return gl_mul_2exp<84>(x);
-    case 8: return gl_mul_2exp<96>(x);
-    case 9: return gl_mul_2exp<108>(x);
-    case 10: return gl_mul_2exp<120>(x);
-    case 11: return gl_mul_2exp<132>(x);
-    case 12: return gl_mul_2exp<144>(x);
-    case 13: return gl_mul_2exp<156>(x);
-    case 14: return gl_mul_2exp<168>(x);
-    default: return gl_mul_2exp<180>(x);
+    case 1: return gl_mul_2exp<3>(x);
+    case 2: return gl_mul_2exp<6>(x);
+    case 3: return gl_mul_2exp<9>(x);
+    case 4: return gl_mul_2exp<12>(x);
+    case 5: return gl_mul_2exp<15>(x);
+    case 6: return gl_mul_2exp<18>(x);
+    case 7: return gl_mul_2exp<21>(x);
+    case 8: return gl_mul_2exp<24>(x);
+    case 9: return gl_mul_2exp<27>(x);
+    case 10: return gl_mul_2exp<30>(x);
+    case 11: return gl_mul_2exp<33>(x);
+    case 12: return gl_mul_2exp<36>(x);
+    case 13: return gl_mul_2exp<39>(x);
+    case 14: return gl_mul_2exp<42>(x);
+    case 15: return gl_mul_2exp<45>(x);
+    case 16: return gl_mul_2exp<48>(x);
+    case 17: return gl_mul_2exp<51>(x);
+    case 18: return gl_mul_2exp<54>(x);
+    case 19: return gl_mul_2exp<57>(x);
+    case 20: return gl_mul_2exp<60>(x);
+    case 21: return gl_mul_2exp<63>(x);
+    case 22: return gl_mul_2exp<66>(x);
+    case 23: return gl_mul_2exp<69>(x);
+    case 24: return gl_mul_2exp<72>(x);
+    case 25: return gl_mul_2exp<75>(x);
+    case 26: return gl_mul_2exp<78>(x);
+    case 27: return gl_mul_2exp<81>(x);
+    case 28: return gl_mul_2exp<84>(x);
+    case 29: return gl_mul_2exp<87>(x);
+    case 30: return gl_mul_2exp<90>(x);
+    case 31: return gl_mul_2exp<93>(x);
+    case 32: return gl_mul_2exp<96>(x);
+    case 33: return gl_mul_2exp<99>(x);
+    case 34: return gl_mul_2exp<102>(x);
+    case 35: return gl_mul_2exp<105>(x);
+    case 36: return gl_mul_2exp<108>(x);
+    case 37: return gl_mul_2exp<111>(x);
+    case 38: return gl_mul_2exp<114>(x);
+    case 39: return gl_mul_2exp<117>(x);
+    case 40: return gl_mul_2exp<120>(x);
+    case 41: return gl_mul_2exp<123>(x);
+    case 42: return gl_mul_2exp<126>(x);
+    case 43: return gl_mul_2exp<129>(x);
+    case 44: return gl_mul_2exp<132>(x);
+    case 45: return gl_mul_2exp<135>(x);
+    case 46: return gl_mul_2exp<138>(x);
+    case 47: return gl_mul_2exp<141>(x);
+    case 48: return gl_mul_2exp<144>(x);
+    case 49: return gl_mul_2exp<147>(x);
+    case 50: return gl_mul_2exp<150>(x);
+    case 51: return gl_mul_2exp<153>(x);
+    case 52: return gl_mul_2exp<156>(x);
+    case 53: return gl_mul_2exp<159>(x);
+    case 54: return gl_mul_2exp<162>(x);
+    case 55: return gl_mul_2exp<165>(x);
+    case 56: return gl_mul_2exp<168>(x);
+    case 57: return gl_mul_2exp<171>(x);
+    case 58: return gl_mul_2exp<174>(x);
+    case 59: return gl_mul_2exp<177>(x);
+    case 60: return gl_mul_2exp<180>(x);
+    case 61: return gl_mul_2exp<183>(x);
+    case 62: return gl_mul_2exp<186>(x);
+    default: return gl_mul_2exp<189>(x);
   }
 }
-// R-point DIF network, R = 2^LOGR <= 16; output X[k] lands in x[bitrev_LOGR(k)].  w_R = 2^(192/R).
+// R-point DIF network, R = 2^LOGR <= 64; output X[k] lands in x[bitrev_LOGR(k)].  w_R = 2^(192/R) = w_64^(64/R).
 template <int LOGR, bool INV>
 __device__ __forceinline__ void dft_small(u64* x) {
   constexpr int R = 1 << LOGR;
@@ -363,9 +411,9 @@ __device__ __forceinline__ void dft_small(u64* x) {
       for (int jj = 0; jj < span; jj++) {
         u64 a = x[g0 + jj], b = x[g0 + jj + span];
         x[g0 + jj] = gl_add(a, b);
-        int e = (jj << s) * (16 >> LOGR);  // twiddle w_R^(jj * 2^s) = 2^(12 e)
-        if (INV) e = (16 - e) & 15;
-        x[g0 + jj + span] = mul_2exp12(gl_sub(a, b), e);
+        int e = (jj << s) * (64 >> LOGR);  // twiddle w_R^(jj * 2^s) = 2^(3 e)
+        if (INV) e = (64 - e) & 63;
+        x[g0 + jj + span] = mul_2exp3(gl_sub(a, b), e);
       }
     }
   }
@@ -492,7 +540,9 @@ void ntt_inverse_tall(const NttTables* T, const NttTallTables* TT, const u64* va
     case 1: outer_inv_launch<1>(values, coeffs, N, TT, ncols, s); break;
     case 2: outer_inv_launch<2>(values, coeffs, N, TT, ncols, s); break;
     case 3: outer_inv_launch<3>(values, coeffs, N, TT, ncols, s); break;
-    default: outer_inv_launch<4>(values, coeffs, N, TT, ncols, s); break;
+    case 4: outer_inv_launch<4>(values, coeffs, N, TT, ncols, s); break;
+    case 5: outer_inv_launch<5>(values, coeffs, N, TT, ncols, s); break;
+    default: outer_inv_launch<6>(values, coeffs, N, TT, ncols, s); break;
   }
   dim3 grid(16, (unsigned)(ncols << log_r)), block(256);
   k_ntt_pass1<true><<<grid, block, 0, s>>>(coeffs, N, tmp, N, nullptr, T->twmat_inv, T->tw256_inv, log_r);
@@ -515,7 +565,9 @@ void ntt_inverse_lde_tall(const NttTables* T, const NttTallTables* TT, const u64
     case 1: outer_inv_launch<1>(values, coeffs, N, TT, ncols, s); break;
     case 2: outer_inv_launch<2>(values, coeffs, N, TT, ncols, s); break;
     case 3: outer_inv_launch<3>(values, coeffs, N, TT, ncols, s); break;
-    default: outer_inv_launch<4>(values, coeffs, N, TT, ncols, s); break;
+    case 4: outer_inv_launch<4>(values, coeffs, N, TT, ncols, s); break;
+    case 5: outer_inv_launch<5>(values, coeffs, N, TT, ncols, s); break;
+    default: outer_inv_launch<6>(values, coeffs, N, TT, ncols, s); break;
   }
   dim3 grid(16, (unsigned)(ncols << log_r)), block(256);
   k_ntt_pass1<true><<<grid, block, 0, s>>>(coeffs, N, tmp, N, nullptr, T->twmat_inv, T->tw256_inv, log_r);
@@ -528,7 +580,9 @@ void ntt_inverse_lde_tall(const NttTables* T, const NttTallTables* TT, const u64
       case 1: outer_fwd_launch<1>(tmp, N, half, 2 * N, TT, h, ncols, s); break;
       case 2: outer_fwd_launch<2>(tmp, N, half, 2 * N, TT, h, ncols, s); break;
       case 3: outer_fwd_launch<3>(tmp, N, half, 2 * N, TT, h, ncols, s); break;
-      default: outer_fwd_launch<4>(tmp, N, half, 2 * N, TT, h, ncols, s); break;
+      case 4: outer_fwd_launch<4>(tmp, N, half, 2 * N, TT, h, ncols, s); break;
+      case 5: outer_fwd_launch<5>(tmp, N, half, 2 * N, TT, h, ncols, s); break;
+      default: outer_fwd_launch<6>(tmp, N, half, 2 * N, TT, h, ncols, s); break;
     }
   }
 }
@@ -545,7 +599,9 @@ void ntt_lde_tall(const NttTables* T, const NttTallTables* TT, const u64* coeffs
       case 1: outer_fwd_launch<1>(tmp, N, half, 2 * N, TT, h, ncols, s); break;
       case 2: outer_fwd_launch<2>(tmp, N, half, 2 * N, TT, h, ncols, s); break;
       case 3: outer_fwd_launch<3>(tmp, N, half, 2 * N, TT, h, ncols, s); break;
-      default: outer_fwd_launch<4>(tmp, N, half, 2 * N, TT, h, ncols, s); break;
+      case 4: outer_fwd_launch<4>(tmp, N, half, 2 * N, TT, h, ncols, s); break;
+      case 5: outer_fwd_launch<5>(tmp, N, half, 2 * N, TT, h, ncols, s); break;
+      default: outer_fwd_launch<6>(tmp, N, half, 2 * N, TT, h, ncols, s); break;
     }
   }
 }

@@ -151,8 +151,8 @@ static int prove_on_slot(bn254s_ctx* c, Slot& sl, int kind, const bn254s_params&
   const size_t N = rows_for(n, P.min_rows_log2);
   unsigned log_n = 0;
   while (((size_t)1 << log_n) < N) log_n++;
-  if (log_n < 16 || log_n > 20) {
-    err = "supported trace heights: 2^16 .. 2^20 rows (up to 2048 instances in one proof)";
+  if (log_n < 16 || log_n > 22) {
+    err = "supported trace heights: 2^16 .. 2^22 rows (up to 8192 instances in one proof)";
     return BN254S_E_UNSUPPORTED;
   }
   if (P.num_challenges != 2 || P.rate_bits != 1 || P.cap_height != 4 || P.arity_bits != 4 || P.min_rows_log2 < 16 ||

@@ -33,3 +33,22 @@ def test_g1_tall_proof_2pow17(gpu_ctx, oracle):
     rc, msg = oracle_lib.verify(oracle, 0, pr.words, degree_bits, s, x, o)
     assert rc == 0, msg
     print("tall G1 (2^17) stage ms:", {k: round(v, 2) for k, v in pr.stage_ms.items()})
+
+
+def test_fq_exp_very_tall_proofs_are_accepted_by_both_verifiers(gpu_ctx, oracle):
+    """N = 2^21 (R = 32 blocks per column: the outer DFT uses w_32 = 2^6) and N = 2^20: too tall for the CPU oracle to
+    prove within a test, so the proof is checked by the oracle's verifier (independent AIR restatement at zeta, FRI, CTL
+    sums) and by the library's own; a corrupted opening is rejected by both."""
+    for n, bits in ((4096, 21), (1100, 20)):
+        s, x = synth.fq_inputs(n, seed=40 + bits)
+        pr = gpu_ctx.prove_fq_exp(s, x)
+        assert pr.degree_bits == bits
+        for k in range(0, n, 397):
+            assert synth.words_to_int(pr.outputs.reshape(-1, 4)[k]) == pow(synth.words_to_int(x[k]), synth.words_to_int(s[k]), synth.P)
+        rc, msg = oracle_lib.verify(oracle, 2, pr.words, bits, s, x)
+        assert rc == 0, msg
+        gpu_ctx.verify(2, pr.words, bits, s, x, None, pr.outputs)
+        bad = pr.words.copy()
+        bad[64 * 3 + 2 * 427 + 2 * 427 + 5] ^= np.uint64(1)  # an auxiliary opening
+        rc, msg = oracle_lib.verify(oracle, 2, bad, bits, s, x)
+        assert rc == 1 and "Mismatch" in msg
