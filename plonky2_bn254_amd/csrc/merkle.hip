@@ -48,10 +48,41 @@ __global__ __launch_bounds__(256) void k_merkle_level(const u64* __restrict__ in
   o[1] = make_ulonglong2(s[2], s[3]);
 }
 
+// ---- small trees: one permutation per 16 lanes (poseidon_permute_coop) ----------------------------------------------------
+static constexpr size_t COOP_MAX_NODES = 16384;  // above this a level fills the GPU with one-lane permutations anyway
+
+__global__ __launch_bounds__(256) void k_merkle_level_coop(const u64* __restrict__ in, u64* __restrict__ out, size_t n_out) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t node = t >> 4;
+  const int l = (int)(t & 15);
+  const bool live = node < n_out;  // whole 16-lane groups are live or not; every lane still runs the permutation
+  u64 s = (live && l < 8) ? in[8 * node + l] : 0;
+  s = poseidon_permute_coop(s, l);
+  if (live && l < 4) out[4 * node + l] = s;
+}
+
+__global__ __launch_bounds__(256) void k_leaf_hash_coop(const u64* __restrict__ data, size_t leaf_stride, size_t elem_stride,
+                                                        int leaf_len, size_t n_leaves, u64* __restrict__ digests) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t j = t >> 4;
+  const int l = (int)(t & 15);
+  const bool live = j < n_leaves;
+  const u64* p = data + (live ? j : 0) * leaf_stride;
+  u64 s = 0;
+  for (int c = 0; c < leaf_len; c += 8) {  // leaf_len > 4 (hash_no_pad: overwrite the rate lanes, permute)
+    if (l < 8 && c + l < leaf_len) s = p[(size_t)(c + l) * elem_stride];
+    s = poseidon_permute_coop(s, l);
+  }
+  if (live && l < 4) digests[4 * j + l] = s;
+}
+
 void merkle_leaves(const u64* data, size_t leaf_stride, size_t elem_stride, int leaf_len, int log_leaves, u64* tree,
                    hipStream_t s) {
   size_t n = (size_t)1 << log_leaves;
-  k_leaf_hash<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(data, leaf_stride, elem_stride, leaf_len, n, tree);
+  if (leaf_len > 4 && n * (size_t)((leaf_len + 7) / 8) <= 4 * COOP_MAX_NODES)  // small trees (FRI layers): latency matters
+    k_leaf_hash_coop<<<(unsigned)((16 * n + 255) / 256), 256, 0, s>>>(data, leaf_stride, elem_stride, leaf_len, n, tree);
+  else
+    k_leaf_hash<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(data, leaf_stride, elem_stride, leaf_len, n, tree);
 }
 
 void merkle_upper(int log_leaves, int cap_height, u64* tree, hipStream_t s) {
@@ -59,7 +90,8 @@ void merkle_upper(int log_leaves, int cap_height, u64* tree, hipStream_t s) {
     size_t n_out = (size_t)1 << (log_leaves - l - 1);
     const u64* in = tree + 4 * merkle_level_offset(log_leaves, l);
     u64* out = tree + 4 * merkle_level_offset(log_leaves, l + 1);
-    k_merkle_level<<<(unsigned)((n_out + 255) / 256), 256, 0, s>>>(in, out, n_out);
+    if (n_out <= COOP_MAX_NODES) k_merkle_level_coop<<<(unsigned)((16 * n_out + 255) / 256), 256, 0, s>>>(in, out, n_out);
+    else k_merkle_level<<<(unsigned)((n_out + 255) / 256), 256, 0, s>>>(in, out, n_out);
   }
 }
 

@@ -169,6 +169,59 @@ GL_HD void poseidon_permute(u64 s[12]) {
 #endif
 }
 
+#if defined(__HIP_DEVICE_COMPILE__)
+// Cooperative permutation for the latency-bound places (upper Merkle levels, FRI layer trees): 16 adjacent lanes work on ONE
+// state, lane l < 12 holding element l (lanes 12..15 idle).  A round is one S-box per lane instead of twelve in sequence and
+// one MDS row per lane (the other eleven elements come through ds_bpermute), so a permutation takes about a fifth of the time
+// of the one-lane form - at five times the instruction count, which is why leaf hashing of the big commitments stays
+// one-lane.  Same field elements as poseidon_permute.  All 64 lanes of the wave must call it.
+__device__ __forceinline__ u64 poseidon_permute_coop(u64 s, int l) {
+  const int lane = (int)(threadIdx.x & 63);
+  const int base = lane & ~15;
+  u32 c2, c8, c16;
+  asm("s_mov_b32 %0, 2" : "=s"(c2));
+  asm("s_mov_b32 %0, 8" : "=s"(c8));
+  asm("s_mov_b32 %0, 16" : "=s"(c16));
+  const u32 C[12] = {17, 15, 41, c16, c2, 28, 13, 13, 39, 18, 34, 20};
+  const int lc = l < 12 ? l : 0;  // idle lanes compute on lane 0's constants; their results are never read
+  // the lane's constants of the next round are fetched while the current round runs (they sit on the critical path otherwise)
+  u64 rc = POSEIDON_RC_DEV[lc], k_lo = POSEIDON_FOLD_DEV[2 * lc], k_hi = POSEIDON_FOLD_DEV[2 * lc + 1];
+#pragma unroll 1
+  for (int rnd = 0; rnd < 30; rnd++) {
+    const int nr = rnd < 29 ? rnd + 1 : 29;
+    const u64 rc_n = POSEIDON_RC_DEV[12 * nr + lc], k_lo_n = POSEIDON_FOLD_DEV[24 * nr + 2 * lc],
+              k_hi_n = POSEIDON_FOLD_DEV[24 * nr + 2 * lc + 1];
+    const bool full = rnd < 4 || rnd >= 26;
+    if (full || l == 0) s = poseidon_sbox_lazy(gl_add_lazy(s, rc));  // partial rounds: lane 0 only, the rest is in k_lo / k_hi
+    u64 al = k_lo, ah = k_hi;                                         // zero in the full rounds
+    const u32 slo = (u32)s, shi = (u32)(s >> 32);
+#pragma unroll
+    for (int k = 0; k < 12; k++) {
+      int src = lc + k;
+      src = base + (src >= 12 ? src - 12 : src);
+      const u32 vlo = (u32)__builtin_amdgcn_ds_bpermute(src << 2, (int)slo);
+      const u32 vhi = (u32)__builtin_amdgcn_ds_bpermute(src << 2, (int)shi);
+      al += (u64)vlo * C[k];
+      ah += (u64)vhi * C[k];
+    }
+    if (l == 0) {
+      al += (u64)slo * c8;
+      ah += (u64)shi * c8;
+    }
+    const u64 t = al + (u64)(u32)(ah >> 32) * 0xFFFFFFFFull;
+    const u64 x = ah << 32;
+    const u64 sum = t + x;
+    s = (sum < x) ? sum + GL_EPS : sum;
+    rc = rc_n;
+    k_lo = k_lo_n;
+    k_hi = k_hi_n;
+  }
+  return s >= GL_P ? s - GL_P : s;
+}
+#else
+__device__ u64 poseidon_permute_coop(u64 s, int l);  // host compilation pass: the kernels only need the declaration
+#endif
+
 GL_HD void poseidon_two_to_one(const u64 l[4], const u64 r[4], u64 out[4]) {
   u64 s[12] = {l[0], l[1], l[2], l[3], r[0], r[1], r[2], r[3], 0, 0, 0, 0};
   poseidon_permute(s);
