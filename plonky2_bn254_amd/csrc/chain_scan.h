@@ -41,14 +41,15 @@ __device__ __forceinline__ P pt_add_complete(const P& p, const P& q) {
 
 // LDS image of a point: word w of lane k at sh[w * 256 + k] (conflict-free for consecutive lanes)
 __device__ __forceinline__ void lds_put_fq(u64* sh, int w0, int k, const fq& v) {
+  const fqw w = fq_pack(v);
 #pragma unroll
-  for (int l = 0; l < 4; l++) sh[(w0 + l) * 256 + k] = v.l[l];
+  for (int l = 0; l < 4; l++) sh[(w0 + l) * 256 + k] = w.l[l];
 }
 __device__ __forceinline__ fq lds_get_fq(const u64* sh, int w0, int k) {
-  fq r;
+  u64 w[4];
 #pragma unroll
-  for (int l = 0; l < 4; l++) r.l[l] = sh[(w0 + l) * 256 + k];
-  return r;
+  for (int l = 0; l < 4; l++) w[l] = sh[(w0 + l) * 256 + k];
+  return fq_unpack(w);
 }
 __device__ __forceinline__ void lds_put(u64* sh, int k, const g1j& p) {
   lds_put_fq(sh, 0, k, p.x);

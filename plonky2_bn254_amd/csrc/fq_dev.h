@@ -1,137 +1,175 @@
-// BN254 base field Fq (4 x 64-bit Montgomery) for gfx950 device code, plus Jacobian G1 arithmetic.
+// BN254 base field Fq for gfx950 device code, plus Jacobian G1 / G2 arithmetic.
 // Replaces ark-bn254 / ark-ff at the reference call sites src/starks/curves/g1/add.rs:56,66,80
 // (affine add, field division) and scalar_mul_stark.rs:105-106.  Only canonical affine coordinates ever
-// leave the device, so the result does not depend on the coordinate system used internally.
+// leave the device, so the result does not depend on the representation used internally.
+//
+// Representation: ten 26-bit limbs in 32-bit registers, Montgomery form with R = 2^260, always canonical (< p, limbs < 2^26).
+// gfx950 needs two wait states between a VALU instruction that writes VCC and an add-with-carry that reads it, so the usual
+// 64-bit-limb carry chains (v_addc_co) spend more issue slots on s_nop than on arithmetic.  With 26-bit limbs a product is
+// 100 + 100 v_mad_u64_u32 into ten 64-bit column sums that cannot overflow (< 2^56), carries are shifts and masks, and
+// comparisons are sign bits: no VCC anywhere.  A multiplication is ~330 instructions instead of ~1000.
 #pragma once
 #include "gl_dev.h"
 
 typedef unsigned __int128 u128;
 
+static constexpr int FQ_NL = 10, FQ_LB = 26;
+static constexpr u32 FQ_MASK = (1u << FQ_LB) - 1;
 struct fq {
+  u32 l[FQ_NL];
+};
+struct fqw {  // 256-bit value as four 64-bit words (storage / wire format)
   u64 l[4];
 };
 
-__device__ static constexpr u64 FQ_P[4] = {0x3c208c16d87cfd47ULL, 0x97816a916871ca8dULL, 0xb85045b68181585dULL, 0x30644e72e131a029ULL};
-__device__ static constexpr u64 FQ_ONE[4] = {0xd35d438dc58f0d9dULL, 0x0a78eb28f5c70b3dULL, 0x666ea36f7879462cULL, 0x0e0a77c19a07df2fULL};
-__device__ static constexpr u64 FQ_R2[4] = {0xf32cfc5b538afa89ULL, 0xb5e71911d44501fbULL, 0x47ab1eff0a417ff6ULL, 0x06d89f71cab8351fULL};
+// p, R mod p, R^2 mod p (R = 2^260) in 26-bit limbs; -p^-1 mod 2^26; p - 2 in 64-bit words (exponent of the inversion)
+__device__ static constexpr u32 FQ_P[FQ_NL] = {0x7cfd47, 0x2305b6, 0xa8d3c2, 0x245a1c7, 0x197816a, 0x605617, 0x1045b68, 0x280a6e1, 0x272e131, 0xc1913};
+__device__ static constexpr u32 FQ_ONE[FQ_NL] = {0x2fce4b4, 0x82203d, 0x9a8455, 0x126eaa6, 0x2498908, 0x63c052, 0x29201d8, 0x1c93e16, 0x24e1bb7, 0x7c590};
+__device__ static constexpr u32 FQ_R2[FQ_NL] = {0x166eb04, 0x22a0746, 0x16b86, 0x1865406, 0x98e615, 0x2d3e263, 0x1531600, 0x265a6ff, 0x1a30d3a, 0x2a11a};
+static constexpr u32 FQ_NINV = 0x866389;
 __device__ static constexpr u64 FQ_PM2[4] = {0x3c208c16d87cfd45ULL, 0x97816a916871ca8dULL, 0xb85045b68181585dULL, 0x30644e72e131a029ULL};
-static constexpr u64 FQ_NINV = 0x87d20782e4866389ULL;
 
 __device__ __forceinline__ fq fq_zero() {
   fq r;
-  r.l[0] = r.l[1] = r.l[2] = r.l[3] = 0;
+#pragma unroll
+  for (int i = 0; i < FQ_NL; i++) r.l[i] = 0;
   return r;
 }
 __device__ __forceinline__ fq fq_one() {
   fq r;
 #pragma unroll
-  for (int i = 0; i < 4; i++) r.l[i] = FQ_ONE[i];
+  for (int i = 0; i < FQ_NL; i++) r.l[i] = FQ_ONE[i];
   return r;
 }
-__device__ __forceinline__ bool fq_is_zero(const fq& a) { return (a.l[0] | a.l[1] | a.l[2] | a.l[3]) == 0; }
+__device__ __forceinline__ bool fq_is_zero(const fq& a) {
+  u32 o = 0;
+#pragma unroll
+  for (int i = 0; i < FQ_NL; i++) o |= a.l[i];
+  return o == 0;
+}
 __device__ __forceinline__ bool fq_eq(const fq& a, const fq& b) {
-  return a.l[0] == b.l[0] && a.l[1] == b.l[1] && a.l[2] == b.l[2] && a.l[3] == b.l[3];
-}
-__device__ __forceinline__ bool fq_geq_p(const u64 t[4]) {
+  u32 o = 0;
 #pragma unroll
-  for (int i = 3; i >= 0; i--) {
-    if (t[i] > FQ_P[i]) return true;
-    if (t[i] < FQ_P[i]) return false;
-  }
-  return true;
+  for (int i = 0; i < FQ_NL; i++) o |= a.l[i] ^ b.l[i];
+  return o == 0;
 }
-__device__ __forceinline__ void fq_sub_p(u64 t[4]) {
-  u64 borrow = 0;
+// t[] = limbs of a 260-bit two's-complement value in (-p, p), borrow = -1 when it is negative: add p back in that case
+__device__ __forceinline__ fq fq_fix_negative(const u32 t[FQ_NL], int borrow) {
+  const u32 mask = (u32)borrow;
+  fq r;
+  int c = 0;
 #pragma unroll
-  for (int i = 0; i < 4; i++) {
-    u128 d = (u128)t[i] - FQ_P[i] - borrow;
-    t[i] = (u64)d;
-    borrow = (u64)(d >> 64) & 1;
+  for (int j = 0; j < FQ_NL; j++) {
+    int v = (int)t[j] + (int)(FQ_P[j] & mask) + c;
+    r.l[j] = (u32)v & FQ_MASK;
+    c = v >> FQ_LB;
   }
+  return r;
 }
 __device__ __forceinline__ fq fq_add(const fq& a, const fq& b) {
-  fq r;
-  u128 c = 0;
+  u32 t[FQ_NL];
+  int c = 0;
 #pragma unroll
-  for (int i = 0; i < 4; i++) {
-    c += (u128)a.l[i] + b.l[i];
-    r.l[i] = (u64)c;
-    c >>= 64;
+  for (int j = 0; j < FQ_NL; j++) {  // a + b - p with a signed carry
+    int v = (int)(a.l[j] + b.l[j]) - (int)FQ_P[j] + c;
+    t[j] = (u32)v & FQ_MASK;
+    c = v >> FQ_LB;
   }
-  if ((u64)c || fq_geq_p(r.l)) fq_sub_p(r.l);  // p < 2^254: no carry out in practice
-  return r;
+  return fq_fix_negative(t, c);
 }
 __device__ __forceinline__ fq fq_sub(const fq& a, const fq& b) {
-  fq r;
-  u64 borrow = 0;
+  u32 t[FQ_NL];
+  int c = 0;
 #pragma unroll
-  for (int i = 0; i < 4; i++) {
-    u128 d = (u128)a.l[i] - b.l[i] - borrow;
-    r.l[i] = (u64)d;
-    borrow = (u64)(d >> 64) & 1;
+  for (int j = 0; j < FQ_NL; j++) {
+    int v = (int)a.l[j] - (int)b.l[j] + c;
+    t[j] = (u32)v & FQ_MASK;
+    c = v >> FQ_LB;
   }
-  if (borrow) {
-    u128 c = 0;
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-      c += (u128)r.l[i] + FQ_P[i];
-      r.l[i] = (u64)c;
-      c >>= 64;
-    }
-  }
-  return r;
+  return fq_fix_negative(t, c);
 }
 __device__ __forceinline__ fq fq_dbl(const fq& a) { return fq_add(a, a); }
-__device__ __forceinline__ fq fq_neg(const fq& a) { return fq_is_zero(a) ? a : fq_sub(fq_zero(), a); }
+__device__ __forceinline__ fq fq_neg(const fq& a) { return fq_sub(fq_zero(), a); }  // -0 = 0: the sum 0 - 0 is not negative
 
-// CIOS Montgomery product a*b*R^-1 mod p.
+// Montgomery product a*b*R^-1 mod p, operand scanning with interleaved reduction in radix 2^26.
 __device__ __forceinline__ fq fq_mul(const fq& a, const fq& b) {
-  u64 t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
+  u64 acc[FQ_NL + 1];
 #pragma unroll
-  for (int i = 0; i < 4; i++) {
-    u128 c;
-    u64 bi = b.l[i];
-    c = (u128)a.l[0] * bi + t0; t0 = (u64)c; c >>= 64;
-    c += (u128)a.l[1] * bi + t1; t1 = (u64)c; c >>= 64;
-    c += (u128)a.l[2] * bi + t2; t2 = (u64)c; c >>= 64;
-    c += (u128)a.l[3] * bi + t3; t3 = (u64)c; c >>= 64;
-    c += t4;
-    t4 = (u64)c;
-    u64 t5 = (u64)(c >> 64);
-    u64 m = t0 * FQ_NINV;
-    c = (u128)m * FQ_P[0] + t0; c >>= 64;
-    c += (u128)m * FQ_P[1] + t1; t0 = (u64)c; c >>= 64;
-    c += (u128)m * FQ_P[2] + t2; t1 = (u64)c; c >>= 64;
-    c += (u128)m * FQ_P[3] + t3; t2 = (u64)c; c >>= 64;
-    c += t4;
-    t3 = (u64)c;
-    t4 = t5 + (u64)(c >> 64);
+  for (int j = 0; j <= FQ_NL; j++) acc[j] = 0;
+#pragma unroll
+  for (int i = 0; i < FQ_NL; i++) {
+    const u32 bi = b.l[i];
+#pragma unroll
+    for (int j = 0; j < FQ_NL; j++) acc[j] += (u64)a.l[j] * bi;
+    const u32 m = ((u32)acc[0] * FQ_NINV) & FQ_MASK;
+#pragma unroll
+    for (int j = 0; j < FQ_NL; j++) acc[j] += (u64)m * FQ_P[j];
+    // acc[0] is now a multiple of 2^26: divide by 2^26 (shift the window down by one limb)
+    const u64 carry = acc[0] >> FQ_LB;
+#pragma unroll
+    for (int j = 0; j < FQ_NL; j++) acc[j] = acc[j + 1];
+    acc[0] += carry;
+    acc[FQ_NL] = 0;
   }
-  fq r;
-  r.l[0] = t0; r.l[1] = t1; r.l[2] = t2; r.l[3] = t3;
-  if (t4 || fq_geq_p(r.l)) fq_sub_p(r.l);
-  return r;
+  // carry propagation: the result is below 2p
+  u32 r[FQ_NL];
+#pragma unroll
+  for (int j = 0; j < FQ_NL - 1; j++) {
+    acc[j + 1] += acc[j] >> FQ_LB;
+    r[j] = (u32)acc[j] & FQ_MASK;
+  }
+  r[FQ_NL - 1] = (u32)acc[FQ_NL - 1];
+  // subtract p once if r >= p
+  u32 t[FQ_NL];
+  int c = 0;
+#pragma unroll
+  for (int j = 0; j < FQ_NL; j++) {
+    int v = (int)r[j] - (int)FQ_P[j] + c;
+    t[j] = (u32)v & FQ_MASK;
+    c = v >> FQ_LB;
+  }
+  const u32 mask = (u32)c;  // all ones: r < p, keep r
+  fq o;
+#pragma unroll
+  for (int j = 0; j < FQ_NL; j++) o.l[j] = (r[j] & mask) | (t[j] & ~mask);
+  return o;
 }
 __device__ __forceinline__ fq fq_sqr(const fq& a) { return fq_mul(a, a); }
 
-__device__ __forceinline__ fq fq_from_canonical(const u64* w) {  // w < p
-  fq t, r2;
+// 26-bit limbs <-> four 64-bit words (value below 2^256)
+__device__ __forceinline__ fq fq_unpack(const u64 w[4]) {
+  fq r;
 #pragma unroll
-  for (int i = 0; i < 4; i++) {
-    t.l[i] = w[i];
-    r2.l[i] = FQ_R2[i];
+  for (int j = 0; j < FQ_NL; j++) {
+    const int bit = FQ_LB * j, k = bit >> 6, sh = bit & 63;
+    u64 v = w[k] >> sh;
+    if (sh + FQ_LB > 64 && k + 1 < 4) v |= w[k + 1] << (64 - sh);
+    r.l[j] = (u32)v & FQ_MASK;
   }
-  return fq_mul(t, r2);
+  return r;
 }
-__device__ __forceinline__ fq fq_to_canonical(const fq& a) {
-  fq one;
+__device__ __forceinline__ fqw fq_pack(const fq& a) {
+  fqw r;
+#pragma unroll
+  for (int k = 0; k < 4; k++) r.l[k] = 0;
+#pragma unroll
+  for (int j = 0; j < FQ_NL; j++) {
+    const int bit = FQ_LB * j, k = bit >> 6, sh = bit & 63;
+    r.l[k] |= (u64)a.l[j] << sh;
+    if (sh + FQ_LB > 64 && k + 1 < 4) r.l[k + 1] |= (u64)a.l[j] >> (64 - sh);
+  }
+  return r;
+}
+__device__ __forceinline__ fq fq_from_canonical(const u64* w) {  // w < p, plain (non-Montgomery) words
+  fq r2;
+#pragma unroll
+  for (int i = 0; i < FQ_NL; i++) r2.l[i] = FQ_R2[i];
+  return fq_mul(fq_unpack(w), r2);
+}
+__device__ __forceinline__ fqw fq_to_canonical(const fq& a) {
+  fq one = fq_zero();
   one.l[0] = 1;
-  one.l[1] = one.l[2] = one.l[3] = 0;
-  return fq_mul(a, one);
-}
-__device__ __forceinline__ fq fq_from_u32(u32 v) {
-  u64 w[4] = {v, 0, 0, 0};
-  return fq_from_canonical(w);
+  return fq_pack(fq_mul(a, one));
 }
 
 // a^(p-2); a != 0.  Not inlined: used once per batch-inversion thread.

@@ -8,15 +8,17 @@
 static constexpr int NPTS = 514;  // per instance: 0 = offset | one, 1+k = C_k (k<256), 257+k = D_k (k<=256)
 
 // ---- SoA vectors of Fq elements: element e, limb l at base[l*count + e] ---------------------------------
+// (the element is stored as the four 64-bit words of its Montgomery residue; registers hold ten 26-bit limbs, fq_dev.h)
 __device__ __forceinline__ fq ld_fq(const u64* base, size_t count, size_t e) {
-  fq r;
+  u64 w[4];
 #pragma unroll
-  for (int l = 0; l < 4; l++) r.l[l] = base[l * count + e];
-  return r;
+  for (int l = 0; l < 4; l++) w[l] = base[l * count + e];
+  return fq_unpack(w);
 }
 __device__ __forceinline__ void st_fq(u64* base, size_t count, size_t e, const fq& v) {
+  const fqw w = fq_pack(v);
 #pragma unroll
-  for (int l = 0; l < 4; l++) base[l * count + e] = v.l[l];
+  for (int l = 0; l < 4; l++) base[l * count + e] = w.l[l];
 }
 
 // index of the highest set bit of s below position k, or -1
@@ -37,7 +39,7 @@ __device__ __forceinline__ int sum_point(const u64 s[4], int k) {
 }
 
 __device__ __forceinline__ void fq_to_limbs(const fq& mont, int limbs[16]) {
-  fq c = fq_to_canonical(mont);
+  const fqw c = fq_to_canonical(mont);
 #pragma unroll
   for (int i = 0; i < 16; i++) limbs[i] = (int)((c.l[i >> 2] >> (16 * (i & 3))) & 0xFFFF);
 }

@@ -354,7 +354,7 @@ __global__ void k_g1_outputs(const u64* __restrict__ scalars, int n, const u64* 
   u64 s[4];
   for (int i = 0; i < 4; i++) s[i] = scalars[4 * inst + i];
   AffPt p = affine_pt(px, py, zi, (size_t)NPTS * n, (size_t)sum_point(s, 256) * n + inst);
-  fq x = fq_to_canonical(p.x), y = fq_to_canonical(p.y);
+  const fqw x = fq_to_canonical(p.x), y = fq_to_canonical(p.y);
   for (int i = 0; i < 4; i++) {
     out8[8 * inst + i] = x.l[i];
     out8[8 * inst + 4 + i] = y.l[i];

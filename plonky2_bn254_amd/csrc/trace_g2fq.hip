@@ -310,7 +310,7 @@ __global__ void k_g2_outputs(const u64* __restrict__ scalars, int n, Soa2 px, So
   u64 s[4];
   for (int i = 0; i < 4; i++) s[i] = scalars[4 * inst + i];
   Aff2 p = affine_pt2(px, py, pz, zni, (size_t)NPTS * n, (size_t)sum_point(s, 256) * n + inst);
-  fq v[4] = {fq_to_canonical(p.x.c0), fq_to_canonical(p.x.c1), fq_to_canonical(p.y.c0), fq_to_canonical(p.y.c1)};
+  const fqw v[4] = {fq_to_canonical(p.x.c0), fq_to_canonical(p.x.c1), fq_to_canonical(p.y.c0), fq_to_canonical(p.y.c1)};
   for (int j = 0; j < 4; j++)
     for (int i = 0; i < 4; i++) out16[16 * inst + 4 * j + i] = v[j].l[i];
 }
@@ -439,7 +439,7 @@ __global__ void k_fq_outputs(const u64* __restrict__ scalars, int n, const u64* 
   if (inst >= n) return;
   u64 s[4];
   for (int i = 0; i < 4; i++) s[i] = scalars[4 * inst + i];
-  fq v = fq_to_canonical(ld_fq(tab, (size_t)NPTS * n, (size_t)sum_point(s, 256) * n + inst));
+  const fqw v = fq_to_canonical(ld_fq(tab, (size_t)NPTS * n, (size_t)sum_point(s, 256) * n + inst));
   for (int i = 0; i < 4; i++) out4[4 * inst + i] = v.l[i];
 }
 
