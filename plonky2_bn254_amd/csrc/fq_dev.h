@@ -91,6 +91,7 @@ __device__ __forceinline__ fq fq_sub(const fq& a, const fq& b) {
 __device__ __forceinline__ fq fq_dbl(const fq& a) { return fq_add(a, a); }
 __device__ __forceinline__ fq fq_neg(const fq& a) { return fq_sub(fq_zero(), a); }  // -0 = 0: the sum 0 - 0 is not negative
 
+__device__ __forceinline__ fq fq_cond_sub_p(const u32 r[FQ_NL]);
 // Montgomery product a*b*R^-1 mod p, operand scanning with interleaved reduction in radix 2^26.
 __device__ __forceinline__ fq fq_mul(const fq& a, const fq& b) {
   u64 acc[FQ_NL + 1];
@@ -119,7 +120,10 @@ __device__ __forceinline__ fq fq_mul(const fq& a, const fq& b) {
     r[j] = (u32)acc[j] & FQ_MASK;
   }
   r[FQ_NL - 1] = (u32)acc[FQ_NL - 1];
-  // subtract p once if r >= p
+  return fq_cond_sub_p(r);
+}
+// r[] (below 2p, limbs normalised) -> canonical
+__device__ __forceinline__ fq fq_cond_sub_p(const u32 r[FQ_NL]) {
   u32 t[FQ_NL];
   int c = 0;
 #pragma unroll
@@ -134,7 +138,34 @@ __device__ __forceinline__ fq fq_mul(const fq& a, const fq& b) {
   for (int j = 0; j < FQ_NL; j++) o.l[j] = (r[j] & mask) | (t[j] & ~mask);
   return o;
 }
-__device__ __forceinline__ fq fq_sqr(const fq& a) { return fq_mul(a, a); }
+// a^2 R^-1: the 55 distinct limb products first (cross terms doubled), then the reduction: 155 multiply-adds instead of 200
+__device__ __forceinline__ fq fq_sqr(const fq& a) {
+  u64 c[2 * FQ_NL];
+#pragma unroll
+  for (int k = 0; k < 2 * FQ_NL; k++) c[k] = 0;
+#pragma unroll
+  for (int i = 0; i < FQ_NL; i++) {
+    c[2 * i] += (u64)a.l[i] * a.l[i];
+    const u32 d = a.l[i] << 1;
+#pragma unroll
+    for (int j = i + 1; j < FQ_NL; j++) c[i + j] += (u64)d * a.l[j];
+  }
+#pragma unroll
+  for (int i = 0; i < FQ_NL; i++) {
+    const u32 m = ((u32)c[i] * FQ_NINV) & FQ_MASK;
+#pragma unroll
+    for (int j = 0; j < FQ_NL; j++) c[i + j] += (u64)m * FQ_P[j];
+    c[i + 1] += c[i] >> FQ_LB;
+  }
+  u32 r[FQ_NL];
+#pragma unroll
+  for (int j = 0; j < FQ_NL - 1; j++) {
+    c[FQ_NL + j + 1] += c[FQ_NL + j] >> FQ_LB;
+    r[j] = (u32)c[FQ_NL + j] & FQ_MASK;
+  }
+  r[FQ_NL - 1] = (u32)c[2 * FQ_NL - 1];
+  return fq_cond_sub_p(r);
+}
 
 // 26-bit limbs <-> four 64-bit words (value below 2^256)
 __device__ __forceinline__ fq fq_unpack(const u64 w[4]) {
