@@ -284,7 +284,7 @@ __device__ __forceinline__ fq2 fq2_sub(const fq2& a, const fq2& b) {
   return r;
 }
 __device__ __forceinline__ fq2 fq2_dbl(const fq2& a) { return fq2_add(a, a); }
-__device__ __noinline__ fq2 fq2_mul(const fq2& a, const fq2& b) {  // Karatsuba: 3 Fq products
+__device__ __forceinline__ fq2 fq2_mul(const fq2& a, const fq2& b) {  // Karatsuba: 3 Fq products
   fq t0 = fq_mul(a.c0, b.c0), t1 = fq_mul(a.c1, b.c1);
   fq t2 = fq_mul(fq_add(a.c0, a.c1), fq_add(b.c0, b.c1));
   fq2 r;
