@@ -196,7 +196,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "u64 (Goldilocks p = 2^64-2^32+1; BN254 Fq as 4x64-bit Montgomery)",
+            "dtype": "u64 (Goldilocks p = 2^64-2^32+1; BN254 Fq as 10x26-bit Montgomery limbs)",
             "data": "synthetic",
             "config": {"workload": "configs[1]: batch of 1024 G1 scalar-muls per GPU per step = 8 proofs x 128 instances, "
                                    "2^16 rows, W=781, standard_fast_config",
