@@ -203,6 +203,7 @@ static int prove_on_slot(bn254s_ctx* c, Slot& sl, int kind, const bn254s_params&
   u64* d_in = mem.words("in", in_words + 16);
   u64* d_tvals = mem.words("tvals", (size_t)W * N);
   u64* d_tcoef = mem.words("tcoef", (size_t)W * N);
+  u64* d_hist = mem.words("hist", 65536 / 2);
   u64* d_tmp = mem.words("tmp", (size_t)(log_r ? 1 : 3) * std::max(W, A) * N);  // [tmp | y0 | y1] for the fused commitment
   d_tmp_fwd = d_tmp;
   u64* d_tlde = mem.words("tlde", (size_t)W * M2);
@@ -238,7 +239,7 @@ static int prove_on_slot(bn254s_ctx* c, Slot& sl, int kind, const bn254s_params&
     }
   }
   u64* d_qout = mem.words("qout", wpq * P.num_queries + 64);
-  if (!d_in || !d_tvals || !d_tcoef || !d_tmp || !d_tlde || !d_trees || !d_avals || !d_acoef || !d_alde || !d_scr || !d_q ||
+  if (!d_hist || !d_in || !d_tvals || !d_tcoef || !d_tmp || !d_tlde || !d_trees || !d_avals || !d_acoef || !d_alde || !d_scr || !d_q ||
       !d_tabs || !d_open || !d_fri || !d_fritrees || !d_qout) {
     err = mem.err;
     return BN254S_E_OOM;
@@ -279,12 +280,18 @@ static int prove_on_slot(bn254s_ctx* c, Slot& sl, int kind, const bn254s_params&
   CHK(hipMemcpyAsync(d_x, x, n * (size_t)PW * 8, hipMemcpyHostToDevice, st));
   if (kind != KIND_FQ) CHK(hipMemcpyAsync(d_off, off, n * (size_t)PW * 8, hipMemcpyHostToDevice, st));
   u64* d_outs = d_open;  // n*PW words fit (reused later)
-  int trc = kind == KIND_G1   ? g1_generate_trace_device(d_sc, d_x, d_off, n, d_tvals, N, d_scr, d_outs, d_err, st)
-            : kind == KIND_G2 ? g2_generate_trace_device(d_sc, d_x, d_off, n, d_tvals, N, d_scr, d_outs, d_err, st)
-                              : fq_generate_trace_device(d_sc, d_x, n, d_tvals, N, d_scr, d_outs, d_err, st);
+  int trc = kind == KIND_G1   ? g1_generate_trace_device(d_sc, d_x, d_off, n, d_tvals, N, d_scr, d_outs, d_err, st, false)
+            : kind == KIND_G2 ? g2_generate_trace_device(d_sc, d_x, d_off, n, d_tvals, N, d_scr, d_outs, d_err, st, false)
+                              : fq_generate_trace_device(d_sc, d_x, n, d_tvals, N, d_scr, d_outs, d_err, st, false);
   if (trc) {
     err = "trace generation launch failed";
     return BN254S_E_HIP;
+  }
+  {
+    // generate_range_checks: the histogram keeps 128 KB of LDS per workgroup on every CU, which would lock another proof's
+    // NTT tiles (35 KB each) out of the CUs it shares: it takes its turn like the other wide kernels
+    BigSection big(c, st, BIG_EXCL);
+    launch_range_columns(d_tvals, N, sh.rc_begin, sh.rc_end, sh.freq_col, sh.table_col, (u32*)d_hist, d_err, st);
   }
   pr->outputs.resize(n * (size_t)PW);
   int h_err = 0;

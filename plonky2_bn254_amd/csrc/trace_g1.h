@@ -21,4 +21,9 @@ static constexpr int MZ_IQP = 0, MZ_QUOT = 1, MZ_LO = 18, MZ_HI = 49, MZ_LEN = 8
 size_t g1_trace_scratch_words(size_t n);
 // All pointers are device pointers; trace is column-major [G1_W][N]; outputs n x 8 canonical words.
 int g1_generate_trace_device(const u64* d_scalars, const u64* d_x, const u64* d_off, size_t n, u64* d_trace, size_t N,
-                             u64* d_scratch, u64* d_outputs, int* d_err, hipStream_t st);
+                             u64* d_scratch, u64* d_outputs, int* d_err, hipStream_t st, bool with_range = true);
+
+// generate_range_checks on a finished trace: histogram of columns [rc_begin, rc_end) -> frequency column, and the range
+// counter column (defined in trace_g1.hip; hist = 65536 u32 of scratch)
+void launch_range_columns(u64* trace, size_t N, int rc_begin, int rc_end, int freq_col, int range_col, u32* hist, int* err,
+                          hipStream_t st);

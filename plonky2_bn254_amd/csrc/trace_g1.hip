@@ -368,7 +368,7 @@ size_t g1_trace_scratch_words(size_t n) {
 }
 
 int g1_generate_trace_device(const u64* d_scalars, const u64* d_x, const u64* d_off, size_t n, u64* d_trace, size_t N,
-                             u64* d_scratch, u64* d_outputs, int* d_err, hipStream_t st) {
+                             u64* d_scratch, u64* d_outputs, int* d_err, hipStream_t st, bool with_range) {
   size_t cnt = (size_t)NPTS * n, nrows = n * 512;
   u64* px = d_scratch;
   u64* py = px + 4 * cnt;
@@ -386,7 +386,8 @@ int g1_generate_trace_device(const u64* d_scalars, const u64* d_x, const u64* d_
   k_g1_row_den<<<(unsigned)((nrows + 63) / 64), 64, 0, st>>>(d_scalars, (int)n, px, py, zi, den);
   launch_fq_batch_inv(den, deninv, nrows, st);
   k_g1_rows<<<(unsigned)((nrows + 63) / 64), 64, 0, st>>>(d_scalars, (int)n, px, py, zi, deninv, rf, d_trace, N, d_err);
-  launch_range_columns(d_trace, N, G1_RC_BEGIN, G1_RC_END, G1_COL_FREQ, G1_COL_RANGE, hist, d_err, st);
+  if (with_range)
+    launch_range_columns(d_trace, N, G1_RC_BEGIN, G1_RC_END, G1_COL_FREQ, G1_COL_RANGE, hist, d_err, st);
   if (d_outputs) k_g1_outputs<<<(unsigned)((n + 63) / 64), 64, 0, st>>>(d_scalars, (int)n, px, py, zi, d_outputs);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }

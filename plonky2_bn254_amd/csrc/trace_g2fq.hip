@@ -321,7 +321,7 @@ size_t g2_trace_scratch_words(size_t n) {
 }
 
 int g2_generate_trace_device(const u64* d_scalars, const u64* d_x, const u64* d_off, size_t n, u64* d_trace, size_t N,
-                             u64* d_scratch, u64* d_outputs, int* d_err, hipStream_t st) {
+                             u64* d_scratch, u64* d_outputs, int* d_err, hipStream_t st, bool with_range) {
   size_t cnt = (size_t)NPTS * n, nrows = n * 512;
   u64* p = d_scratch;
   auto take = [&](size_t words) {
@@ -344,7 +344,8 @@ int g2_generate_trace_device(const u64* d_scalars, const u64* d_x, const u64* d_
   k_g2_row_den<<<(unsigned)((nrows + 63) / 64), 64, 0, st>>>(d_scalars, (int)n, px, py, pz, zni, inv_in);
   launch_fq_batch_inv(inv_in, inv_out, 3 * nrows, st);
   k_g2_rows<<<(unsigned)((nrows + 63) / 64), 64, 0, st>>>(d_scalars, (int)n, px, py, pz, zni, inv_out, rf, d_trace, N, d_err);
-  launch_range_columns(d_trace, N, G2L::RC_BEGIN, G2L::RC_END, G2L::FREQ, G2L::RANGE, hist, d_err, st);
+  if (with_range)
+    launch_range_columns(d_trace, N, G2L::RC_BEGIN, G2L::RC_END, G2L::FREQ, G2L::RANGE, hist, d_err, st);
   if (d_outputs) k_g2_outputs<<<(unsigned)((n + 63) / 64), 64, 0, st>>>(d_scalars, (int)n, px, py, pz, zni, d_outputs);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
@@ -446,7 +447,7 @@ __global__ void k_fq_outputs(const u64* __restrict__ scalars, int n, const u64* 
 size_t fq_trace_scratch_words(size_t n) { return 4 * (size_t)NPTS * n + 1024 + 65536 / 2; }
 
 int fq_generate_trace_device(const u64* d_scalars, const u64* d_x, size_t n, u64* d_trace, size_t N, u64* d_scratch,
-                             u64* d_outputs, int* d_err, hipStream_t st) {
+                             u64* d_outputs, int* d_err, hipStream_t st, bool with_range) {
   size_t cnt = (size_t)NPTS * n, nrows = n * 512;
   u64* tab = d_scratch;
   u64* rf = tab + 4 * cnt;
@@ -455,7 +456,8 @@ int fq_generate_trace_device(const u64* d_scalars, const u64* d_x, size_t n, u64
   launch_round_flag_table(rf, st);
   k_fq_chain<<<(unsigned)((n + 63) / 64), 64, 0, st>>>(d_scalars, d_x, (int)n, tab);
   k_fq_rows<<<(unsigned)((nrows + 63) / 64), 64, 0, st>>>(d_scalars, (int)n, tab, rf, d_trace, N, d_err);
-  launch_range_columns(d_trace, N, FQL::RC_BEGIN, FQL::RC_END, FQL::FREQ, FQL::RANGE, hist, d_err, st);
+  if (with_range)
+    launch_range_columns(d_trace, N, FQL::RC_BEGIN, FQL::RC_END, FQL::FREQ, FQL::RANGE, hist, d_err, st);
   if (d_outputs) k_fq_outputs<<<(unsigned)((n + 63) / 64), 64, 0, st>>>(d_scalars, (int)n, tab, d_outputs);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
