@@ -10,7 +10,7 @@ __host__ __device__ inline size_t merkle_level_offset_dev(int log_leaves, int le
 // Partial evaluations per (polynomial, block k1 < R): out[(p*R + k1)*5 ..] = {S(zeta^R).c0,.c1, S((g zeta)^R).c0,.c1, sum};
 // P(z) = sum_k1 z^k1 S_k1(z^R), P(1) = sum_k1 sums (coefficients in the transposed layout of ntt.h)
 // power tables of the two opening points (zeta, g zeta) for k_openings: FRI_OPENING_TABLE_WORDS words, built on the device
-static constexpr size_t FRI_OPENING_ZQ_WORDS = 2 * 256 * 2, FRI_OPENING_TABLE_WORDS = 2 * FRI_OPENING_ZQ_WORDS;
+static constexpr size_t FRI_OPENING_ZQ_WORDS = 2 * 256 * 4, FRI_OPENING_TABLE_WORDS = 2 * FRI_OPENING_ZQ_WORDS;
 void fri_opening_tables(unsigned log_r, gl2 zeta, gl2 zeta_next, u64* d_tables, hipStream_t st);
 void fri_openings(const u64* d_coeffs, size_t N, unsigned log_r, int npolys, const u64* d_tables, u64* d_out, hipStream_t st);
 

@@ -25,14 +25,18 @@
 // out[(p*R + k1)*5 ..] = {S0.c0, S0.c1, S1.c0, S1.c1, sum of the block's coefficients}
 static constexpr int OPEN_Q = (int)(65536 / 256);
 
-// zq[(pt*OPEN_Q + q)*2 ..] = ((z_pt^R)^256)^q, zt[(pt*256 + t)*2 ..] = (z_pt^R)^t
+// zq3[(pt*OPEN_Q + q)*8 ..] = 22-bit limbs of the two components of ((z_pt^R)^256)^q (3 + 3 u32, padded to 8),
+// zt[(pt*256 + t)*2 ..] = (z_pt^R)^t
 __global__ __launch_bounds__(256) void k_opening_tables(gl2 z0r, gl2 z1r, u64* __restrict__ zq, u64* __restrict__ zt) {
   const int t = threadIdx.x;
+  u32* zq3 = reinterpret_cast<u32*>(zq);
   for (int pt = 0; pt < 2; pt++) {
     const gl2 z = pt ? z1r : z0r;
     gl2 a = gl2_pow(gl2_pow(z, 256), (u64)t), b = gl2_pow(z, (u64)t);
-    zq[(pt * OPEN_Q + t) * 2] = a.c0;
-    zq[(pt * OPEN_Q + t) * 2 + 1] = a.c1;
+    const W3 a0 = w3_split(a.c0), a1 = w3_split(a.c1);
+    u32* e = zq3 + (size_t)(pt * OPEN_Q + t) * 8;
+    e[0] = a0.w0; e[1] = a0.w1; e[2] = a0.w2; e[3] = 0;
+    e[4] = a1.w0; e[5] = a1.w1; e[6] = a1.w2; e[7] = 0;
     zt[(pt * 256 + t) * 2] = b.c0;
     zt[(pt * 256 + t) * 2 + 1] = b.c1;
   }
@@ -44,25 +48,38 @@ __global__ __launch_bounds__(256) void k_openings(const u64* __restrict__ coeffs
   const int t = threadIdx.x;
   const size_t M = N >> log_r;  // = 65536
   const u64* c = coeffs + (size_t)blockIdx.x * N + (size_t)blockIdx.y * M;
-  Acc2 a0, a1;
-  acc2_init(a0);
-  acc2_init(a1);
-  u64 s_lo = 0, s_hi = 0;
-#pragma unroll 4
+  Acc3 a00, a01, a10, a11, as;  // (point, component); `as` sums the coefficients themselves (weight 1)
+  acc3_init(a00);
+  acc3_init(a01);
+  acc3_init(a10);
+  acc3_init(a11);
+  u64 s0 = 0, s1 = 0, s2 = 0;
+  const u32* zq3 = reinterpret_cast<const u32*>(zq);
+#pragma unroll 8
   for (int q = 0; q < OPEN_Q; q++) {
     const u64 v = c[(size_t)t + 256 * (size_t)q];
-    acc2_mad(a0, v, zq[2 * q], zq[2 * q + 1]);
-    acc2_mad(a1, v, zq[2 * (OPEN_Q + q)], zq[2 * (OPEN_Q + q) + 1]);
-    s_lo += v;
-    s_hi += s_lo < v ? 1 : 0;
+    const u32 v0 = (u32)v & M22, v1 = (u32)(v >> 22) & M22, v2 = (u32)(v >> 44);
+    const u32* e0 = zq3 + (size_t)q * 8;
+    const u32* e1 = zq3 + (size_t)(OPEN_Q + q) * 8;
+    acc3_mad(a00, v0, v1, v2, e0[0], e0[1], e0[2]);
+    acc3_mad(a01, v0, v1, v2, e0[4], e0[5], e0[6]);
+    acc3_mad(a10, v0, v1, v2, e1[0], e1[1], e1[2]);
+    acc3_mad(a11, v0, v1, v2, e1[4], e1[5], e1[6]);
+    s0 += v0;
+    s1 += v1;
+    s2 += v2;
   }
-  gl2 r0 = gl2_mul(gl2_make(acc_red(a0.a0), acc_red(a0.a1)), gl2_make(zt[2 * t], zt[2 * t + 1]));
-  gl2 r1 = gl2_mul(gl2_make(acc_red(a1.a0), acc_red(a1.a1)), gl2_make(zt[2 * (256 + t)], zt[2 * (256 + t) + 1]));
+  acc3_init(as);
+  as.c[0] = s0;
+  as.c[1] = s1;
+  as.c[2] = s2;
+  gl2 r0 = gl2_mul(gl2_make(acc3_red(a00), acc3_red(a01)), gl2_make(zt[2 * t], zt[2 * t + 1]));
+  gl2 r1 = gl2_mul(gl2_make(acc3_red(a10), acc3_red(a11)), gl2_make(zt[2 * (256 + t)], zt[2 * (256 + t) + 1]));
   red[t] = r0.c0;
   red[256 + t] = r0.c1;
   red[512 + t] = r1.c0;
   red[768 + t] = r1.c1;
-  red[1024 + t] = gl_reduce128(s_lo, s_hi);
+  red[1024 + t] = acc3_red(as);
   __syncthreads();
   for (int off = 128; off > 0; off >>= 1) {
     if (t < off)
@@ -86,7 +103,7 @@ struct CombineArgs {
   const u64* tl;   // trace LDE [W][2N]
   const u64* al;   // aux LDE [A][2N]
   const u64* ql;   // quotient LDE [4][2N]
-  const u64* apow; // alpha^j as (c0,c1) pairs, j < W + A + 4
+  const u32* apow3; // alpha^j cut in 22-bit limbs: 8 u32 per j = (c0: w0 w1 w2 -, c1: w0 w1 w2 -), j < W + A + 4
   const u64* xs;   // x_j (bit-reversed order)
   int W, A, num_lookup;
   gl2 zeta, zeta_next;
@@ -100,24 +117,34 @@ __global__ __launch_bounds__(256) void k_fri_combine(CombineArgs A) {
   const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= A.M2) return;
   const size_t M2 = A.M2;
-  Acc2 g;  // a0 = c0 component, a1 = c1 component of sum alpha^j v_j
-  acc2_init(g);
-  for (int c = 0; c < A.W; c++) acc2_mad(g, A.tl[(size_t)c * M2 + j], A.apow[2 * c], A.apow[2 * c + 1]);
-  const u64* ap = A.apow + 2 * A.W;
-  Acc2 gz;
-  acc2_init(gz);
-  for (int c = 0; c < A.A; c++) {
+  // sum alpha^j v_j, components c0 / c1 (Acc3: carry-free columns, weights through scalar loads)
+  Acc3 g0, g1, z0, z1, q0, q1;
+  acc3_init(g0);
+  acc3_init(g1);
+  acc3_init(z0);
+  acc3_init(z1);
+  acc3_init(q0);
+  acc3_init(q1);
+  auto mad2 = [&](Acc3& a0, Acc3& a1, u64 v, const u32* e) {
+    const u32 v0 = (u32)v & M22, v1 = (u32)(v >> 22) & M22, v2 = (u32)(v >> 44);
+    acc3_mad(a0, v0, v1, v2, e[0], e[1], e[2]);
+    acc3_mad(a1, v0, v1, v2, e[4], e[5], e[6]);
+  };
+#pragma unroll 8
+  for (int c = 0; c < A.W; c++) mad2(g0, g1, A.tl[(size_t)c * M2 + j], A.apow3 + 8 * (size_t)c);  // unrolled: loads in flight
+  const u32* ap = A.apow3 + 8 * (size_t)A.W;
+#pragma unroll 8
+  for (int c = 0; c < A.num_lookup; c++) mad2(g0, g1, A.al[(size_t)c * M2 + j], ap + 8 * (size_t)c);
+  for (int c = A.num_lookup; c < A.A; c++) {  // the CTL Z columns also enter the batch opened at 1
     u64 v = A.al[(size_t)c * M2 + j];
-    acc2_mad(g, v, ap[2 * c], ap[2 * c + 1]);
-    if (c >= A.num_lookup) acc2_mad(gz, v, A.apow[2 * (c - A.num_lookup)], A.apow[2 * (c - A.num_lookup) + 1]);
+    mad2(g0, g1, v, ap + 8 * (size_t)c);
+    mad2(z0, z1, v, A.apow3 + 8 * (size_t)(c - A.num_lookup));
   }
-  gl2 f1 = gl2_make(acc_red(g.a0), acc_red(g.a1));
-  ap = A.apow + 2 * (A.W + A.A);
-  Acc2 gq;
-  acc2_init(gq);
-  for (int c = 0; c < 4; c++) acc2_mad(gq, A.ql[(size_t)c * M2 + j], ap[2 * c], ap[2 * c + 1]);
-  gl2 f0 = gl2_add(f1, gl2_make(acc_red(gq.a0), acc_red(gq.a1)));
-  gl2 f2 = gl2_make(acc_red(gz.a0), acc_red(gz.a1));
+  gl2 f1 = gl2_make(acc3_red(g0), acc3_red(g1));
+  ap = A.apow3 + 8 * (size_t)(A.W + A.A);
+  for (int c = 0; c < 4; c++) mad2(q0, q1, A.ql[(size_t)c * M2 + j], ap + 8 * (size_t)c);
+  gl2 f0 = gl2_add(f1, gl2_make(acc3_red(q0), acc3_red(q1)));
+  gl2 f2 = gl2_make(acc3_red(z0), acc3_red(z1));
   const u64 x = A.xs[j];
   gl2 xe = gl2_make(x, 0);
   gl2 t0 = gl2_mul(gl2_sub(f0, A.r0), gl2_inv(gl2_sub(xe, A.zeta)));
@@ -133,7 +160,7 @@ void fri_combine(const StarkShape& sh, const u64* d_tl, const u64* d_al, const u
   A.tl = d_tl;
   A.al = d_al;
   A.ql = d_ql;
-  A.apow = d_apow;
+  A.apow3 = reinterpret_cast<const u32*>(d_apow);
   A.xs = d_xs;
   A.W = sh.W;
   A.A = sh.n_aux();

@@ -215,7 +215,7 @@ static int prove_on_slot(bn254s_ctx* c, Slot& sl, int kind, const bn254s_params&
   const size_t trace_scr = kind == KIND_G1 ? g1_trace_scratch_words(n) : kind == KIND_G2 ? g2_trace_scratch_words(n) : fq_trace_scratch_words(n);
   u64* d_scr = mem.words("scratch", std::max(trace_scr, aux_scratch_words(sh, N)));
   u64* d_q = mem.words("quot", (size_t)(3 * NQ) * N + (size_t)NQ * M2 + (size_t)QUOTIENT_MAX_PARTS * 2 * M2);  // qv, ab, qcoef, qlde, partials
-  u64* d_tabs = mem.words("tabs", 2 * (size_t)K + 10 * 2 * 80 + 2 * (size_t)(W + A + NQ));
+  u64* d_tabs = mem.words("tabs", 2 * (size_t)K + 10 * 2 * 80 + 4 * (size_t)(W + A + NQ));  // W, mzt, apow (8 u32 per power)
   u64* d_open = mem.words("open", std::max((size_t)(W + A + NQ) * R * 5 + FRI_OPENING_TABLE_WORDS, n * (size_t)PW));
   // FRI layer values (extension, 2 words) and trees
   size_t fri_words = 0, fri_tree_words = 0;
@@ -464,17 +464,19 @@ static int prove_on_slot(bn254s_ctx* c, Slot& sl, int kind, const bn254s_params&
   // ---- FRI (prove_openings) ------------------------------------------------------------------------------------
   gl2 fri_alpha = ch.challenge_ext();
   {
-    std::vector<u64> apow(2 * (size_t)(W + A + NQ));
+    std::vector<u32> apow(8 * (size_t)(W + A + NQ), 0);  // alpha^p cut in 22-bit limbs (quotient_common.h W3), 8 u32 per power
     gl2 ap = gl2_make(1, 0), r0 = gl2_make(0, 0), r1 = r0, r2 = r0;
     for (int p = 0; p < W + A + NQ; p++) {
-      apow[2 * p] = ap.c0;
-      apow[2 * p + 1] = ap.c1;
+      const W3 s0 = w3_split(ap.c0), s1 = w3_split(ap.c1);
+      u32* e = &apow[8 * (size_t)p];
+      e[0] = s0.w0; e[1] = s0.w1; e[2] = s0.w2;
+      e[4] = s1.w0; e[5] = s1.w1; e[6] = s1.w2;
       r0 = gl2_add(r0, gl2_mul(ap, gl2_make(op(p, 0), op(p, 1))));
       if (p < W + A) r1 = gl2_add(r1, gl2_mul(ap, gl2_make(op(p, 2), op(p, 3))));
       if (p < n_ctlz) r2 = gl2_add(r2, gl2_mul_base(ap, op(W + num_lookup + p, 4)));
       ap = gl2_mul(ap, fri_alpha);
     }
-    CHK(hipMemcpyAsync(d_apow, apow.data(), apow.size() * 8, hipMemcpyHostToDevice, st));
+    CHK(hipMemcpyAsync(d_apow, apow.data(), apow.size() * 4, hipMemcpyHostToDevice, st));
     CHK(hipStreamSynchronize(st));
     BigSection big(c, st, BIG_EXCL);
     sb(ST_FRI);
