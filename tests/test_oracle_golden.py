@@ -223,3 +223,18 @@ def test_g2_and_fq_traces_satisfy_their_airs(oracle, kind, name, n_constraints):
             assert synth.g2_from_words(outs[i]) == synth.g2_scalar_mul_offset(si, synth.g2_from_words(x[i]), synth.g2_from_words(o[i]))
         else:
             assert synth.words_to_int(outs[i]) == pow(synth.words_to_int(x[i]), si, synth.P)
+
+
+def test_oracle_reproduces_the_committed_proof_digest(oracle):
+    """tests/golden/proof_digests.json pins the oracle's whole Fq-exp proof transcript (the GPU proofs are compared with the
+    same file in tests/test_gpu_golden.py): a change in the oracle cannot silently move the goal posts."""
+    import hashlib
+    import json
+    import os
+    from plonky2_bn254_amd import synth
+    from tests import oracle_lib
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "proof_digests.json")))["fq_exp"]
+    s, x = synth.fq_inputs(g["n"], seed=g["seed"])
+    proof, outs, _, degree_bits = oracle_lib.prove(oracle, 2, s, x)
+    assert degree_bits == g["degree_bits"] and proof.size == g["n_words"]
+    assert hashlib.sha256(np.ascontiguousarray(proof, dtype="<u8").tobytes()).hexdigest() == g["sha256_proof_words"]
