@@ -30,6 +30,29 @@ def fq_edge_inputs(n=6):
     return s, x
 
 
+def test_fq_arithmetic_limb_boundaries(gpu_ctx, oracle):
+    """Field elements that sit on the carry boundaries of the 26-bit-limb representation of csrc/fq_dev.h (all-ones limbs,
+    p - 1, p - 2^k, 2^(26 j) +- 1, R mod p ...): the whole Fq-exp trace (which squares and multiplies them 256 times) must
+    equal the oracle's, and the outputs Python's pow()."""
+    P = synth.P
+    vals = [P - 1, P - 2, (P - 1) // 2, (P + 1) // 2, (1 << 253) + 12345, (1 << 254) % P, pow(2, 260, P), pow(2, 520, P), P - (1 << 26),
+            P - (1 << 52) + 1]
+    vals += [(1 << (26 * j)) - 1 for j in range(1, 10)] + [(1 << (26 * j)) + 1 for j in range(1, 10)] + [(1 << (26 * j)) % P for j in (9, 10)]
+    vals += [sum(((1 << 26) - 1) << (26 * j) for j in range(9)), sum(0x2AAAAAA << (26 * j) for j in range(9)) % P]
+    n = len(vals)
+    s, x = synth.fq_inputs(n, seed=77)
+    for i, v in enumerate(vals):
+        x[i] = synth._to_words(v % P)
+    s[1] = synth._to_words(P - 2)          # inversion by exponentiation
+    s[2] = synth._to_words((1 << 256) - 1)
+    ref, ref_out = oracle_lib.generate_trace(oracle, 2, s, x)
+    got, got_out = gpu_ctx.generate_trace(2, s, x)
+    bad = np.argwhere(got != ref)
+    assert bad.size == 0, f"first mismatches (col,row): {bad[:10].tolist()}"
+    for i in range(n):
+        assert synth.words_to_int(got_out[i]) == pow(synth.words_to_int(x[i]), synth.words_to_int(s[i]), P), i
+
+
 def test_g2_trace_matches_oracle(gpu_ctx, oracle):
     s, x, o = g2_edge_inputs()
     ref, ref_out = oracle_lib.generate_trace(oracle, 1, s, x, o)
