@@ -46,6 +46,18 @@ template <int OP> __global__ void k(u64* out, u32 a0, u32 b0) {
 #define M(y) asm volatile("v_mul_u32_u24 %0, %0, %1" : "+v"(y) : "v"(b));
       M(y0) M(y1) M(y2) M(y3) M(y4) M(y5) M(y6) M(y7)
 #undef M
+    } else if (OP == 10) {  // v_perm_b32
+#define M(y) asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(y) : "v"(a), "v"(b));
+      M(y0) M(y1) M(y2) M(y3) M(y4) M(y5) M(y6) M(y7)
+#undef M
+    } else if (OP == 11) {  // v_lshl_add_u64
+#define M(x) asm volatile("v_lshl_add_u64 %0, %0, 0, %1" : "+v"(x) : "v"(x7));
+      M(x0) M(x1) M(x2) M(x3) M(x4) M(x5) M(x6) M(x0)
+#undef M
+    } else if (OP == 12) {  // v_lshl_add_u32
+#define M(y) asm volatile("v_lshl_add_u32 %0, %0, 3, %1" : "+v"(y) : "v"(b));
+      M(y0) M(y1) M(y2) M(y3) M(y4) M(y5) M(y6) M(y7)
+#undef M
     } else if (OP == 9) {  // v_mad_i64_i32
 #define M(x) asm volatile("v_mad_i64_i32 %0, vcc, %1, %2, %0" : "+v"(x) : "v"(a), "v"(b) : "vcc");
       M(x0) M(x1) M(x2) M(x3) M(x4) M(x5) M(x6) M(x7)
@@ -69,6 +81,6 @@ template <int OP> void run(const char* name, int insts_per_macro) {
 }
 int main() {
   run<6>("v_add_u32", 1); run<3>("v_mad_u32_u24", 1); run<8>("v_mul_u32_u24", 1); run<1>("v_mul_lo_u32", 1); run<2>("v_mul_hi_u32", 1);
-  run<0>("v_mad_u64_u32", 1); run<9>("v_mad_i64_i32", 1); run<4>("add64 (2 insts)", 2); run<5>("v_lshlrev_b64", 1); run<7>("v_dot4_u32_u8", 1);
+  run<0>("v_mad_u64_u32", 1); run<9>("v_mad_i64_i32", 1); run<4>("add64 (2 insts)", 2); run<5>("v_lshlrev_b64", 1); run<7>("v_dot4_u32_u8", 1); run<10>("v_perm_b32", 1); run<11>("v_lshl_add_u64", 1); run<12>("v_lshl_add_u32", 1);
   return 0;
 }
