@@ -61,6 +61,7 @@ void bn254s_ctx_destroy(bn254s_ctx* c) {
     hipStreamSynchronize(s->st);
     s->mem.release();
     if (s->pinned) hipHostFree(s->pinned);
+    for (auto& e : s->events) hipEventDestroy(e);
     hipStreamDestroy(s->st);
     delete s;
   }

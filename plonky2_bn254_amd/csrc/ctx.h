@@ -44,6 +44,7 @@ struct Slot {
   BufPool mem;
   void* pinned = nullptr;  // pinned host staging buffer
   size_t pinned_bytes = 0;
+  std::vector<hipEvent_t> events;  // stage begin / end pairs, created on first use and kept for the slot's lifetime
 };
 
 enum { BIG_NTT = 0, BIG_EXCL = 1, BIG_HASH = 2 };

@@ -260,14 +260,15 @@ static int prove_on_slot(bn254s_ctx* c, Slot& sl, int kind, const bn254s_params&
   u64* d_apow = d_mzt + 10 * 2 * 80;
   const size_t cap_off = 4 * merkle_level_offset(log_m2, log_m2 - P.cap_height);
 
-  hipEvent_t ev[2 * ST_COUNT];
-  for (auto& e : ev) CHK(hipEventCreate(&e));
+  if (sl.events.empty()) {
+    sl.events.resize(2 * ST_COUNT);
+    for (auto& e : sl.events) CHK(hipEventCreate(&e));
+  }
+  hipEvent_t* ev = sl.events.data();
   // one begin/end event pair per stage; a stage's time never includes waiting for the big-kernel lock
   auto sb = [&](int stage) { hipEventRecord(ev[2 * stage], st); };
   auto se = [&](int stage) { hipEventRecord(ev[2 * stage + 1], st); };
-  auto cleanup_events = [&]() {
-    for (auto& e : ev) hipEventDestroy(e);
-  };
+  auto cleanup_events = [&]() {};  // the events belong to the slot
 
   // ---- trace generation (scalar_mul_stark.rs:55-69) ---------------------------------------------------------
   sb(ST_TOTAL);
