@@ -3,7 +3,7 @@ set -e
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 mkdir -p gpurun_out/insts
-rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES -d gpurun_out/insts -o i --output-format csv -- python3 tools/run_proofs.py 2 single > gpurun_out/insts/run.log 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES -d gpurun_out/insts -o i --output-format csv -- python3 ${INSTS_CMD:-tools/run_proofs.py 2 single} > gpurun_out/insts/run.log 2>&1
 python3 - <<'PY'
 import csv, collections
 acc = collections.defaultdict(lambda: collections.defaultdict(float)); calls = collections.Counter()
