@@ -133,6 +133,18 @@ int bn254s_verify(bn254s_ctx* ctx, int kind, const bn254s_params* params, uint32
 int bn254s_ctl_values(int kind, const uint64_t* scalars, const uint64_t* x, const uint64_t* offset, const uint64_t* outputs,
                       size_t n, uint64_t* in_rows, uint64_t* out_rows);
 
+/* map_to_g2 of n Fq2 elements u (8 words: c0, c1) - reference src/utils/hash_to_g2.rs:113-148 and its circuit :150-207, the
+ * pipeline of BASELINE config 5: the Shallue-van de Woestijne candidates and the signed square root are computed on the device,
+ * the two Legendre symbols per input are proven as Fq exponentiations ((p-1)/2, norm(g(x_i))), the cofactor is cleared by a
+ * proven G2 scalar multiplication cofactor * (x, y) + offset, and output - offset is returned.
+ * offsets: n non-infinity G2 points (what set_random_g2 supplies), 16 words each.  out_points: n x 16 words.
+ * fq_jobs (may be NULL): 2n x 8 words (scalar | x) of the Legendre jobs; g2_jobs (may be NULL): n x 20 words (scalar | point)
+ * of the cofactor-clearing jobs - the claimed inputs bn254s_verify needs.  fq_proofs: ceil(2n / 128) proofs, g2_proofs:
+ * ceil(n / 128) proofs, each to be released with bn254s_proof_free. */
+int bn254s_map_to_g2(bn254s_ctx* ctx, const bn254s_params* params, const uint64_t* u, const uint64_t* offsets, size_t n,
+                     uint64_t* out_points, uint64_t* fq_jobs, uint64_t* g2_jobs, bn254s_proof** fq_proofs,
+                     bn254s_proof** g2_proofs);
+
 /* ---- kernel-level entry points (parity tests and bench.py's roofline leg) ------------------------------ */
 /* PolynomialBatch::from_values on host column-major values[C][2^16]: outputs (any may be NULL)
  * coeffs[C][N], lde[C][2N] in Merkle-leaf (bit-reversed) order, cap[16*4]. */

@@ -61,6 +61,7 @@ def load_library():
     lib.bn254s_stage_name.restype = C.c_char_p
     lib.bn254s_proof_free.argtypes = [vp]
     lib.bn254s_verify.argtypes = [vp, C.c_int, C.POINTER(Params), C.c_uint32, vp, C.c_size_t, vp, vp, vp, vp, C.c_size_t]
+    lib.bn254s_map_to_g2.argtypes = [vp, C.POINTER(Params), vp, vp, C.c_size_t, vp, vp, vp, C.POINTER(vp), C.POINTER(vp)]
     lib.bn254s_ctl_values.argtypes = [C.c_int, vp, vp, vp, vp, C.c_size_t, vp, vp]
     lib.bn254s_commit_values.argtypes = [vp, vp, C.c_size_t, vp, vp, vp]
     lib.bn254s_bench_ntt.argtypes = [vp, C.c_size_t, C.c_int, C.POINTER(C.c_float)]
@@ -189,6 +190,21 @@ class Context:
         if rc == -8:
             raise VerifyError(self._lib.bn254s_last_error(self._h).decode())
         self._check(rc, "bn254s_verify")
+
+    def map_to_g2(self, u, offsets, params: Optional[Params] = None):
+        """u [n,8], offsets [n,16] -> (points [n,16], fq_jobs [2n,8], g2_jobs [n,20], fq proofs, g2 proofs): the config-5
+        pipeline on the device (csrc/map_to_g2.hip)."""
+        params = params or default_params()
+        n = u.shape[0]
+        pts = np.zeros((n, 16), np.uint64)
+        fq_jobs = np.zeros((2 * n, 8), np.uint64)
+        g2_jobs = np.zeros((n, 20), np.uint64)
+        n_fq, n_g2 = (2 * n + 127) // 128, (n + 127) // 128
+        pf, pg = (C.c_void_p * n_fq)(), (C.c_void_p * n_g2)()
+        self._check(self._lib.bn254s_map_to_g2(self._h, C.byref(params), _ptr(u), _ptr(offsets), n, _ptr(pts), _ptr(fq_jobs),
+                                               _ptr(g2_jobs), pf, pg), "bn254s_map_to_g2")
+        return (pts, fq_jobs, g2_jobs, [Proof(self._lib, C.c_void_p(pf[i])) for i in range(n_fq)],
+                [Proof(self._lib, C.c_void_p(pg[i])) for i in range(n_g2)])
 
     def ctl_values(self, kind, scalars, x, offset, outputs):
         """(input rows [n, 81|145|33], output rows [n, 33|65|17]): the extra looking values of the two CTLs."""

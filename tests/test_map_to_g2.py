@@ -67,3 +67,31 @@ def test_pipeline_on_gpu(gpu_ctx):
     outs = pg.outputs.reshape(-1, 16)
     for k, (pt, off) in enumerate(pts):
         assert m2g.finish(outs[k], off) == synth.g2_mul(m2g.COFACTOR, pt)
+
+
+@pytest.mark.gpu
+def test_device_front_end_matches_python(gpu_ctx):
+    """bn254s_map_to_g2 (csrc/map_to_g2.hip): candidates, Legendre jobs, selected points with their signed square roots and
+    the final images equal the Python front-end's, and every proof verifies against the job arrays Python derives."""
+    import numpy as np
+    n = 70  # 140 Legendre jobs: two Fq-exp proofs (128 + 12), one G2 proof
+    us = m2g.inputs(n, seed=41)
+    u = np.array([synth._to_words(a[0]) + synth._to_words(a[1]) for a in us], dtype=np.uint64)
+    fs, fx = m2g.fq_exp_jobs(us)
+    legendre = [pow(synth.words_to_int(w), (synth.P - 1) // 2, synth.P) for w in fx]
+    gs, gx, goff, pts = m2g.g2_jobs(us, legendre, seed=9)
+    out, fq_jobs, g2_jobs, pf, pg = gpu_ctx.map_to_g2(u, goff)
+    assert np.array_equal(fq_jobs[:, :4], fs) and np.array_equal(fq_jobs[:, 4:], fx)
+    assert np.array_equal(g2_jobs[:, :4], gs) and np.array_equal(g2_jobs[:, 4:], gx)
+    assert len(pf) == 2 and len(pg) == 1
+    picks = set()
+    for k, (pt, off) in enumerate(pts):
+        assert m2g.finish(pg[0].outputs.reshape(-1, 16)[k], off) == synth.g2_from_words(out[k])
+        picks.add(0 if legendre[2 * k] == 1 else 1 if legendre[2 * k + 1] == 1 else 2)
+    for k in range(0, n, 23):  # python G2 scalar multiplication is slow: spot-check the images
+        assert synth.g2_from_words(out[k]) == synth.g2_mul(m2g.COFACTOR, pts[k][0])
+    assert picks == {0, 1, 2}  # all three branches of the map taken
+    for i, p in enumerate(pf):
+        lo, hi = 128 * i, min(128 * (i + 1), 2 * n)
+        gpu_ctx.verify(2, p.words, p.degree_bits, fs[lo:hi], fx[lo:hi], None, p.outputs)
+    gpu_ctx.verify(1, pg[0].words, pg[0].degree_bits, gs, gx, goff, pg[0].outputs)
