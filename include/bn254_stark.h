@@ -145,6 +145,10 @@ int bn254s_map_to_g2(bn254s_ctx* ctx, const bn254s_params* params, const uint64_
                      uint64_t* out_points, uint64_t* fq_jobs, uint64_t* g2_jobs, bn254s_proof** fq_proofs,
                      bn254s_proof** g2_proofs);
 
+/* hash_to_fq2 (src/utils/hash_to_g2.rs:76-87): Poseidon challenger over `len` Goldilocks elements -> u in Fq2 (8 words), the
+ * input of bn254s_map_to_g2; together they are the reference's hash_to_g2.  Host only, no context. */
+int bn254s_hash_to_fq2(const uint64_t* input, size_t len, uint64_t* out /* 8 */);
+
 /* ---- kernel-level entry points (parity tests and bench.py's roofline leg) ------------------------------ */
 /* PolynomialBatch::from_values on host column-major values[C][2^16]: outputs (any may be NULL)
  * coeffs[C][N], lde[C][2N] in Merkle-leaf (bit-reversed) order, cap[16*4]. */

@@ -14,6 +14,7 @@
 #include <vector>
 #include "ctx.h"
 #include "fq_dev.h"
+#include "transcript.h"
 #include "../../include/bn254_stark.h"
 #include "map_to_g2_constants.inc"
 
@@ -174,6 +175,45 @@ __global__ __launch_bounds__(64) void k_m2g_finish(const u64* __restrict__ o, co
   } while (0)
 
 }  // namespace
+
+// hash_to_fq2 (src/utils/hash_to_g2.rs:76-87): Challenger::observe_elements(input); each coordinate = the low 32 bits of 16
+// challenges as little-endian limbs of a 512-bit integer, reduced modulo p (f_slice_to_biguint, :226-240, then `.into()`).
+extern "C" int bn254s_hash_to_fq2(const uint64_t* input, size_t len, uint64_t* out) {
+  if ((!input && len) || !out) return BN254S_E_INVALID_ARG;
+  static const u64 PW[4] = {0x3c208c16d87cfd47ULL, 0x97816a916871ca8dULL, 0xb85045b68181585dULL, 0x30644e72e131a029ULL};
+  Challenger ch;
+  ch.observe_n(input, len);
+  for (int coord = 0; coord < 2; coord++) {
+    u32 limbs[16];
+    for (int i = 0; i < 16; i++) limbs[i] = (u32)ch.challenge();
+    u64 r[4] = {0, 0, 0, 0};  // r = value mod p, one bit at a time from the top (r < p < 2^254: the doubling cannot overflow)
+    for (int bit = 511; bit >= 0; bit--) {
+      u64 carry = (limbs[bit >> 5] >> (bit & 31)) & 1;
+      for (int w = 0; w < 4; w++) {
+        u64 nc = r[w] >> 63;
+        r[w] = (r[w] << 1) | carry;
+        carry = nc;
+      }
+      bool ge = true;
+      for (int w = 3; w >= 0; w--) {
+        if (r[w] != PW[w]) {
+          ge = r[w] > PW[w];
+          break;
+        }
+      }
+      if (ge) {
+        u64 borrow = 0;
+        for (int w = 0; w < 4; w++) {
+          unsigned __int128 d = (unsigned __int128)r[w] - PW[w] - borrow;
+          r[w] = (u64)d;
+          borrow = (u64)(d >> 64) & 1;
+        }
+      }
+    }
+    memcpy(out + 4 * coord, r, 32);
+  }
+  return BN254S_OK;
+}
 
 extern "C" int bn254s_map_to_g2(bn254s_ctx* c, const bn254s_params* params, const uint64_t* u, const uint64_t* offsets, size_t n,
                                 uint64_t* out_points, uint64_t* fq_jobs, uint64_t* g2_jobs, bn254s_proof** fq_proofs,

@@ -62,6 +62,7 @@ def load_library():
     lib.bn254s_proof_free.argtypes = [vp]
     lib.bn254s_verify.argtypes = [vp, C.c_int, C.POINTER(Params), C.c_uint32, vp, C.c_size_t, vp, vp, vp, vp, C.c_size_t]
     lib.bn254s_map_to_g2.argtypes = [vp, C.POINTER(Params), vp, vp, C.c_size_t, vp, vp, vp, C.POINTER(vp), C.POINTER(vp)]
+    lib.bn254s_hash_to_fq2.argtypes = [vp, C.c_size_t, vp]
     lib.bn254s_ctl_values.argtypes = [C.c_int, vp, vp, vp, vp, C.c_size_t, vp, vp]
     lib.bn254s_commit_values.argtypes = [vp, vp, C.c_size_t, vp, vp, vp]
     lib.bn254s_bench_ntt.argtypes = [vp, C.c_size_t, C.c_int, C.POINTER(C.c_float)]

@@ -162,3 +162,60 @@ def inputs(n: int, seed: int = 0x706C6F6E6B7932 + 5):
     """n uniform Fq2 inputs u."""
     rng = synth.Xoshiro256ss(seed)
     return [(rng.next_u256() % P, rng.next_u256() % P) for _ in range(n)]
+
+
+# ---- hash_to_fq2 (hash_to_g2.rs:76-87): pure-Python mirror of bn254s_hash_to_fq2 -------------------------------------------
+GL_P = 0xFFFFFFFF00000001
+_MDS = [17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20]
+
+
+def _round_constants():
+    import os
+    import re
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "poseidon_constants.inc")
+    return [int(h, 16) for h in re.findall(r"0x([0-9a-fA-F]{16})ULL", open(path).read())]
+
+
+def poseidon_permute(state, rc=None):
+    rc = rc or _round_constants()
+    s = list(state)
+    for rnd in range(30):
+        s = [(s[i] + rc[12 * rnd + i]) % GL_P for i in range(12)]
+        if rnd < 4 or rnd >= 26:
+            s = [pow(v, 7, GL_P) for v in s]
+        else:
+            s[0] = pow(s[0], 7, GL_P)
+        s = [(sum(s[(i + r) % 12] * _MDS[i] for i in range(12)) + (8 * s[0] if r == 0 else 0)) % GL_P for r in range(12)]
+    return s
+
+
+def hash_to_fq2(inputs):
+    """plonky2 Challenger (overwrite-mode duplex sponge, rate 8): observe the inputs, draw 2 x 16 challenges; a coordinate
+    is the little-endian 512-bit integer of the challenges' low 32 bits, modulo p."""
+    rc = _round_constants()
+    state, buf, out = [0] * 12, [], []
+
+    def duplex():
+        nonlocal state, buf, out
+        for i, v in enumerate(buf):
+            state[i] = v
+        buf = []
+        state = poseidon_permute(state, rc)
+        out = state[:8]
+
+    for v in inputs:
+        out = []
+        buf.append(int(v) % GL_P)
+        if len(buf) == 8:
+            duplex()
+
+    def challenge():
+        if buf or not out:
+            duplex()
+        return out.pop()
+
+    res = []
+    for _ in range(2):
+        limbs = [challenge() & 0xFFFFFFFF for _ in range(16)]
+        res.append(sum(v << (32 * i) for i, v in enumerate(limbs)) % P)
+    return tuple(res)

@@ -95,3 +95,19 @@ def test_device_front_end_matches_python(gpu_ctx):
         lo, hi = 128 * i, min(128 * (i + 1), 2 * n)
         gpu_ctx.verify(2, p.words, p.degree_bits, fs[lo:hi], fx[lo:hi], None, p.outputs)
     gpu_ctx.verify(1, pg[0].words, pg[0].degree_bits, gs, gx, goff, pg[0].outputs)
+
+
+def test_hash_to_fq2_host_function_matches_python():
+    """bn254s_hash_to_fq2 (host code of the library: Poseidon challenger + 512-bit reduction) against the pure-Python mirror,
+    for inputs that end inside and on a rate boundary."""
+    import numpy as np
+    from plonky2_bn254_amd import lib as L
+    lib = L.load_library()
+    rng = synth.Xoshiro256ss(5)
+    for n in (0, 1, 7, 8, 9, 16, 23):
+        inp = np.array([rng.next_u64() % m2g.GL_P for _ in range(n)], dtype=np.uint64)
+        out = np.zeros(8, np.uint64)
+        assert lib.bn254s_hash_to_fq2(L._ptr(inp) if n else None, n, L._ptr(out)) == 0
+        got = (synth.words_to_int(out[:4]), synth.words_to_int(out[4:]))
+        assert got == m2g.hash_to_fq2(inp.tolist()), n
+        assert got[0] < synth.P and got[1] < synth.P
