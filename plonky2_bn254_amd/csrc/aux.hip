@@ -148,3 +148,9 @@ void aux_build(const StarkShape& sh, const u64* d_trace, size_t N, const u64 bet
   k_ctl_terms<<<g3, 256, 0, st>>>(d_trace, N, sh.ctl, betas[0], gammas[0], betas[1], gammas[1], cterms, d_err);
   k_scan<<<2 * sh.n_ctl, 1024, 0, st>>>(cterms, N, d_aux + (size_t)2 * (m + 1) * N, N, N, 1);
 }
+
+// loads this translation unit's code object (the HIP runtime defers that to the first launch otherwise)
+void aux_module_warm() {
+  hipFuncAttributes a;
+  (void)hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_logup_terms));
+}

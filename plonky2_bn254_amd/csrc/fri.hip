@@ -314,3 +314,9 @@ __global__ __launch_bounds__(256) void k_gather_queries(QueryGatherArgs A) {
 void fri_gather_queries(const QueryGatherArgs& A, int n_queries, hipStream_t st) {
   k_gather_queries<<<n_queries, 256, 0, st>>>(A);
 }
+
+// loads this translation unit's code object (the HIP runtime defers that to the first launch otherwise)
+void fri_module_warm() {
+  hipFuncAttributes a;
+  (void)hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_opening_tables));
+}

@@ -605,3 +605,9 @@ void ntt_lde_tall(const NttTables* T, const NttTallTables* TT, const u64* coeffs
     }
   }
 }
+
+// loads this translation unit's code object (the HIP runtime defers that to the first launch otherwise)
+void ntt_module_warm() {
+  hipFuncAttributes a;
+  (void)hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_coset_unscale));
+}

@@ -236,3 +236,9 @@ void g1_quotient_launch(const QArgs& A0, const StarkShape& sh, hipStream_t st) {
   k_quotient_g1_sched<<<g, 256, 0, st>>>(A);
   quotient_finish_launch(A, sh, st);
 }
+
+// loads this translation unit's code object (the HIP runtime defers that to the first launch otherwise)
+void quotient_g1_module_warm() {
+  hipFuncAttributes a;
+  (void)hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_point_tables));
+}

@@ -232,3 +232,9 @@ void fq_quotient_launch(const QArgs& A0, const StarkShape& sh, hipStream_t st) {
   k_quotient_fq_sched<<<g, 256, 0, st>>>(A);
   quotient_finish_launch(A, sh, st);
 }
+
+// loads this translation unit's code object (the HIP runtime defers that to the first launch otherwise)
+void quotient_g2fq_module_warm() {
+  hipFuncAttributes a;
+  (void)hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_quotient_fq_sched));
+}

@@ -391,3 +391,9 @@ int g1_generate_trace_device(const u64* d_scalars, const u64* d_x, const u64* d_
   if (d_outputs) k_g1_outputs<<<(unsigned)((n + 63) / 64), 64, 0, st>>>(d_scalars, (int)n, px, py, zi, d_outputs);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
+
+// loads this translation unit's code object (the HIP runtime defers that to the first launch otherwise)
+void trace_g1_module_warm() {
+  hipFuncAttributes a;
+  (void)hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_range_columns));
+}

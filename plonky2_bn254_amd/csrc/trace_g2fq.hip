@@ -461,3 +461,9 @@ int fq_generate_trace_device(const u64* d_scalars, const u64* d_x, size_t n, u64
   if (d_outputs) k_fq_outputs<<<(unsigned)((n + 63) / 64), 64, 0, st>>>(d_scalars, (int)n, tab, d_outputs);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
+
+// loads this translation unit's code object (the HIP runtime defers that to the first launch otherwise)
+void trace_g2fq_module_warm() {
+  hipFuncAttributes a;
+  (void)hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_fq_chain));
+}
