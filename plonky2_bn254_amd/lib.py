@@ -60,6 +60,8 @@ def load_library():
     lib.bn254s_stage_name.argtypes = [C.c_size_t]
     lib.bn254s_stage_name.restype = C.c_char_p
     lib.bn254s_proof_free.argtypes = [vp]
+    lib.bn254s_proof_serialize.argtypes = [vp, vp, C.c_size_t]
+    lib.bn254s_proof_serialize.restype = C.c_size_t
     lib.bn254s_verify.argtypes = [vp, C.c_int, C.POINTER(Params), C.c_uint32, vp, C.c_size_t, vp, vp, vp, vp, C.c_size_t]
     lib.bn254s_map_to_g2.argtypes = [vp, C.POINTER(Params), vp, vp, C.c_size_t, vp, vp, vp, C.POINTER(vp), C.POINTER(vp)]
     lib.bn254s_hash_to_fq2.argtypes = [vp, C.c_size_t, vp]
@@ -101,6 +103,13 @@ class Proof:
         ms, k = C.POINTER(C.c_float)(), C.c_size_t()
         lib.bn254s_proof_stage_ms(handle, C.byref(ms), C.byref(k))
         self.stage_ms = {lib.bn254s_stage_name(i).decode(): float(ms[i]) for i in range(k.value)}
+
+    def serialize(self) -> bytes:
+        """Little-endian bytes of the word layout (bn254s_proof_serialize)."""
+        need = self._lib.bn254s_proof_serialize(self._h, None, 0)
+        buf = C.create_string_buffer(need)
+        assert self._lib.bn254s_proof_serialize(self._h, buf, need) == need
+        return buf.raw
 
     def close(self):
         if self._h:

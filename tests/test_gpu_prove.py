@@ -110,6 +110,16 @@ def test_argument_errors(gpu_ctx):
     assert pr.words.size == 135841
 
 
+def test_serialized_bytes_are_the_little_endian_words(gpu_ctx):
+    s, x, o = synth.g1_inputs(2, seed=3)
+    pr = gpu_ctx.prove_g1(s, x, o)
+    raw = pr.serialize()
+    assert len(raw) == 8 * pr.words.size
+    assert np.array_equal(np.frombuffer(raw, dtype="<u8"), pr.words)
+    # a proof rebuilt from the bytes verifies
+    gpu_ctx.verify(0, np.frombuffer(raw, dtype="<u8").copy(), pr.degree_bits, s, x, o, pr.outputs)
+
+
 def test_identical_instances_and_repeated_calls_are_deterministic(gpu_ctx):
     """128 copies of one job (maximally colliding range-check histogram) and two runs byte-compare."""
     s, x, o = synth.g1_inputs(1, seed=21)
