@@ -99,3 +99,20 @@ def test_plain_c_host_program(tmp_path):
     r = subprocess.run([build_c_example(tmp_path)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "bn254s_verify: 0" in r.stdout and "corrupted proof: -8" in r.stdout
+
+
+def test_batch_results_do_not_depend_on_the_number_of_slots(gpu_ctx, monkeypatch):
+    """BN254S_SLOTS (proofs in flight) and the scheduler costs are throughput knobs only: the proofs must be the same."""
+    s, x, o = synth.g1_inputs(128 * 2 + 5, seed=17)  # three proofs, the last one padded
+    ref = None
+    for slots, cap in (("1", None), ("3", "4"), ("8", None)):
+        monkeypatch.setenv("BN254S_SLOTS", slots)
+        proofs = gpu_ctx.prove_g1_batch(s, x, o)
+        words = [p.words.copy() for p in proofs]
+        assert len(words) == 3
+        if ref is None:
+            ref = words
+        for a, b in zip(words, ref):
+            assert np.array_equal(a, b), slots
+    single = gpu_ctx.prove_g1(s[256:], x[256:], o[256:])
+    assert np.array_equal(single.words, ref[2])
