@@ -55,15 +55,14 @@ struct bn254s_ctx : BufPool {
   NttTables ntt;
   std::vector<Slot*> slots;
   std::map<unsigned, NttTallTables*> tall;  // per log_n
-  // GPU-saturating kernels (NTT, leaf hashing, quotient, ...) of different slots are serialised with this lock:
-  // they cannot run faster side by side, and alone they give clean per-kernel timings.  Latency-bound
-  // kernels (EC chain, upper Merkle levels, scans, PoW) run outside it and overlap freely.
+  // The GPU-filling sections of the proofs in flight take turns through the semaphore below; latency-bound kernels
+  // (doubling chain, upper Merkle levels, scans, PoW, FRI folds) run outside it and overlap freely.
   std::mutex big_mu;
   std::condition_variable big_cv;
   // Weighted semaphore over the GPU-filling sections of all proofs in flight.  Classes (cost out of big_cap = 3):
   //   BIG_NTT  (3): the NTT/LDE stage runs alone - it is the stage the roofline figure is quoted on;
-  //   BIG_EXCL (2): quotient, auxiliary columns, openings, FRI combine - one at a time, but a leaf-hash launch may fill
-  //                 the SIMDs beside it;
+  //   BIG_EXCL (2): quotient, auxiliary columns, range-check histogram, openings, FRI combine - one at a time, but a
+  //                 leaf-hash launch may fill the SIMDs beside it;
   //   BIG_HASH (1): Poseidon leaf hashing - one 2^17-leaf launch puts only two waves on a SIMD, up to three run together.
   // BN254S_BIG_CAP / BN254S_BIG_COST_NTT / BN254S_BIG_COST_EXCL / BN254S_BIG_COST_HASH override the costs (tuning only).
   int big_cap = 3, big_cost[3] = {3, 2, 1}, big_used = 0;
