@@ -161,3 +161,20 @@ def test_g2_and_fq_exp(gpu_ctx, oracle, kind):
     s2[1, 3] ^= np.uint64(1 << 40)
     mine, ref = both_verify(gpu_ctx, oracle, p, s=s2)
     assert mine == "CTL sum mismatch" and ref == "CTL sum mismatch"
+
+
+def test_non_default_query_count_and_grinding(gpu_ctx):
+    """num_queries and pow_bits of StarkConfig are parameters of both the prover and the verifier (FriConfig): a proof made with
+    20 queries and 10 grinding bits verifies under the same parameters only."""
+    s, x, o = synth.g1_inputs(3, seed=61)
+    p = pk.default_params()
+    p.num_queries, p.pow_bits = 20, 10
+    pr = gpu_ctx.prove_g1(s, x, o, params=p)
+    assert pr.words.size < 135841
+    gpu_ctx.verify(0, pr.words, pr.degree_bits, s, x, o, pr.outputs, params=p)
+    with pytest.raises(pk.VerifyError, match="bad proof shape"):
+        gpu_ctx.verify(0, pr.words, pr.degree_bits, s, x, o, pr.outputs)
+    q = pk.default_params()
+    q.num_queries, q.pow_bits = 20, 24  # same shape, stricter grinding: the witness found for 10 bits does not pass
+    with pytest.raises(pk.VerifyError, match="proof of work"):
+        gpu_ctx.verify(0, pr.words, pr.degree_bits, s, x, o, pr.outputs, params=q)
