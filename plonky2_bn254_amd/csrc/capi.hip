@@ -61,6 +61,14 @@ int bn254s_ctx_create(int device_id, bn254s_ctx** out) {
     delete c;
     return BN254S_E_OOM;
   }
+  {  // first use of the pinned device -> host copy path sets up runtime state (~8 ms): not inside the first proof either
+    void* h = nullptr;
+    if (hipHostMalloc(&h, 256 << 10) == hipSuccess) {
+      (void)hipMemcpyAsync(h, c->ntt.twmat_fwd, 256 << 10, hipMemcpyDeviceToHost, c->stream);  // (a 512 KB table)
+      (void)hipStreamSynchronize(c->stream);
+      hipHostFree(h);
+    }
+  }
   // code objects are loaded lazily, one per translation unit: do it now rather than inside the first proof
   ntt_module_warm();
   merkle_module_warm();
