@@ -98,6 +98,11 @@ int bn254s_prove_g1_batch(bn254s_ctx* ctx, const bn254s_params* params, const ui
 int bn254s_prove_batch(bn254s_ctx* ctx, int kind, const bn254s_params* params, const uint64_t* scalars, const uint64_t* x,
                        const uint64_t* offset, size_t n_total, size_t per_proof, bn254s_proof** proofs_out);
 
+/* Several GPUs from one process: proof i is proven by ctxs[i mod n_ctx] (one context per GPU); no inter-GPU traffic.
+ * Same arguments and results as bn254s_prove_batch otherwise. */
+int bn254s_prove_batch_multi(bn254s_ctx** ctxs, size_t n_ctx, int kind, const bn254s_params* params, const uint64_t* scalars,
+                             const uint64_t* x, const uint64_t* offset, size_t n_total, size_t per_proof, bn254s_proof** proofs);
+
 /* Same for G2 (points n x 16 words: x.c0, x.c1, y.c0, y.c1): src/generators/g2/stark_proof.rs:136-179. */
 int bn254s_prove_g2(bn254s_ctx* ctx, const bn254s_params* params, const uint64_t* scalars, const uint64_t* x,
                     const uint64_t* offset, size_t n, bn254s_proof** out);

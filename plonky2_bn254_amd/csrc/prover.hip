@@ -730,6 +730,54 @@ static int prove_one(bn254s_ctx* c, int kind, const bn254s_params* params, const
   *out = pr;
   return BN254S_OK;
 }
+// One process, several GPUs: proof i goes to context i mod n_ctx (proofs share no state), each context
+// pipelines its share exactly like bn254s_prove_batch.  No inter-GPU traffic.
+int bn254s_prove_batch_multi(bn254s_ctx** ctxs, size_t n_ctx, int kind, const bn254s_params* params, const uint64_t* scalars,
+                             const uint64_t* x, const uint64_t* off, size_t n_total, size_t per_proof, bn254s_proof** proofs_out) {
+  if (!ctxs || n_ctx == 0 || kind < 0 || kind > 2 || !params || !scalars || !x || (kind != KIND_FQ && !off) || !proofs_out ||
+      n_total == 0 || per_proof == 0)
+    return BN254S_E_INVALID_ARG;
+  for (size_t g = 0; g < n_ctx; g++)
+    if (!ctxs[g]) return BN254S_E_INVALID_ARG;
+  const size_t n_proofs = (n_total + per_proof - 1) / per_proof;
+  const size_t PW = point_words(kind);
+  for (size_t i = 0; i < n_proofs; i++) proofs_out[i] = nullptr;
+  std::vector<int> rcs(n_ctx, BN254S_OK);
+  std::vector<std::thread> th;
+  for (size_t g = 0; g < n_ctx; g++)
+    th.emplace_back([&, g]() {
+      // gather this context's share into contiguous job arrays (proof i of the share = global proof g + i * n_ctx)
+      std::vector<u64> ls, lx, lo;
+      std::vector<size_t> ids;
+      for (size_t i = g; i < n_proofs; i += n_ctx) {
+        const size_t b = i * per_proof, cnt = std::min(per_proof, n_total - b);
+        if (cnt != per_proof && i + 1 != n_proofs) continue;  // (only the very last proof may be short)
+        ids.push_back(i);
+        ls.insert(ls.end(), scalars + 4 * b, scalars + 4 * (b + cnt));
+        lx.insert(lx.end(), x + PW * b, x + PW * (b + cnt));
+        if (off) lo.insert(lo.end(), off + PW * b, off + PW * (b + cnt));
+      }
+      if (ids.empty()) return;
+      // a short last proof must stay last in its share: it is, since shares are in increasing global order
+      std::vector<bn254s_proof*> out(ids.size(), nullptr);
+      rcs[g] = bn254s_prove_batch(ctxs[g], kind, params, ls.data(), lx.data(), off ? lo.data() : nullptr, ls.size() / 4, per_proof,
+                                  out.data());
+      if (rcs[g] == BN254S_OK)
+        for (size_t k = 0; k < ids.size(); k++) proofs_out[ids[k]] = out[k];
+    });
+  for (auto& t : th) t.join();
+  int rc = BN254S_OK;
+  for (size_t g = 0; g < n_ctx; g++)
+    if (rcs[g] != BN254S_OK && rc == BN254S_OK) rc = rcs[g];
+  if (rc != BN254S_OK)
+    for (size_t i = 0; i < n_proofs; i++)
+      if (proofs_out[i]) {
+        delete proofs_out[i];
+        proofs_out[i] = nullptr;
+      }
+  return rc;
+}
+
 int bn254s_prove_g2(bn254s_ctx* c, const bn254s_params* params, const uint64_t* scalars, const uint64_t* x, const uint64_t* off,
                     size_t n, bn254s_proof** out) {
   return prove_one(c, KIND_G2, params, scalars, x, off, n, out);

@@ -53,6 +53,8 @@ def load_library():
     lib.bn254s_generate_trace.argtypes = [vp, C.c_int, vp, vp, vp, C.c_size_t, C.c_uint32, vp, vp]
     lib.bn254s_prove_g1_batch.argtypes = [vp, C.POINTER(Params), vp, vp, vp, C.c_size_t, C.c_size_t, C.POINTER(vp)]
     lib.bn254s_prove_batch.argtypes = [vp, C.c_int, C.POINTER(Params), vp, vp, vp, C.c_size_t, C.c_size_t, C.POINTER(vp)]
+    lib.bn254s_prove_batch_multi.argtypes = [C.POINTER(vp), C.c_size_t, C.c_int, C.POINTER(Params), vp, vp, vp, C.c_size_t,
+                                             C.c_size_t, C.POINTER(vp)]
     lib.bn254s_proof_words.argtypes = [vp, C.POINTER(U64P), C.POINTER(C.c_size_t)]
     lib.bn254s_proof_outputs.argtypes = [vp, C.POINTER(U64P), C.POINTER(C.c_size_t)]
     lib.bn254s_proof_degree_bits.argtypes = [vp]
@@ -277,3 +279,19 @@ class Context:
         self._check(self._lib.bn254s_g1_generate_trace(self._h, _ptr(scalars), _ptr(x), _ptr(offset), n, min_rows_log2,
                                                        _ptr(trace), _ptr(outs)), "bn254s_g1_generate_trace")
         return trace, outs
+
+
+def prove_batch_multi(contexts, kind, scalars, x, offset=None, per_proof=128, params: Optional[Params] = None):
+    """bn254s_prove_batch_multi: proof i on contexts[i % len(contexts)] (one Context per GPU), one process."""
+    params = params or default_params()
+    lib = contexts[0]._lib
+    n = scalars.shape[0]
+    k = (n + per_proof - 1) // per_proof
+    handles = (C.c_void_p * len(contexts))(*[c._h for c in contexts])
+    outs = (C.c_void_p * k)()
+    rc = lib.bn254s_prove_batch_multi(handles, len(contexts), kind, C.byref(params), _ptr(scalars), _ptr(x), _ptr(offset), n, per_proof,
+                                      outs)
+    if rc != 0:
+        raise RuntimeError(f"bn254s_prove_batch_multi failed with {rc}: " + "; ".join(c._lib.bn254s_last_error(c._h).decode()
+                                                                                     for c in contexts))
+    return [Proof(lib, C.c_void_p(outs[i])) for i in range(k)]

@@ -116,3 +116,23 @@ def test_batch_results_do_not_depend_on_the_number_of_slots(gpu_ctx, monkeypatch
             assert np.array_equal(a, b), slots
     single = gpu_ctx.prove_g1(s[256:], x[256:], o[256:])
     assert np.array_equal(single.words, ref[2])
+
+
+def test_multi_context_batch_matches_single_context(gpu_ctx):
+    """bn254s_prove_batch_multi: proofs dealt round-robin to several contexts (one per GPU in production; two on the same GPU
+    here) come back in order and identical to the one-context batch, including a short last proof."""
+    s, x, o = synth.g1_inputs(128 * 4 + 9, seed=29)
+    ref = [p.words.copy() for p in gpu_ctx.prove_g1_batch(s, x, o)]
+    a, b = pk.Context(0), pk.Context(0)
+    got = pk.prove_batch_multi([a, b], 0, s, x, o)
+    assert len(got) == len(ref) == 5
+    for g, r in zip(got, ref):
+        assert np.array_equal(g.words, r)
+    # errors of one context fail the call as a whole
+    bad_o = o.copy()
+    bad_o[130] = neg_point_words(x[130])
+    with pytest.raises(RuntimeError, match="-4"):
+        pk.prove_batch_multi([a, b], 0, s, x, bad_o)
+    del got
+    a.close()
+    b.close()
