@@ -1,11 +1,18 @@
 #!/usr/bin/env python3
 """bench.py - G1 scalar-mul STARK proofs/sec on MI355X (BASELINE.json metric).
 
-A "step" = one pass of the hot path over one batch of synthetic input: BASELINE.json configs[1],
-"Batch 1024 G1 scalar-muls, full trace-gen+NTT+Merkle+FRI on 1 MI355X", i.e. 8 independent 2^16-row
-proofs of 128 instances each (the reference's own test shape, scalar_mul_stark.rs:554,569) per GPU
-per step.  Independent proofs shard across GPUs with no data-path collective (weak scaling: every rank
-proves its own 1024 instances); RCCL is used only to all-gather the Merkle caps of every proof.
+A "step" = one pass of the hot path over one batch of synthetic input per GPU:
+  * N = 1 : BASELINE.json configs[1], "Batch 1024 G1 scalar-muls, full trace-gen+NTT+Merkle+FRI on 1 MI355X" = 8
+    independent 2^16-row proofs of 128 instances each (the reference's own test shape, scalar_mul_stark.rs:554,569);
+  * N > 1 : configs[3], "Batch 16384 G1 scalar-muls sharded across 8 MI355X" = 2048 instances = 16 proofs per GPU per
+    step (N = 8 is literally configs[3]; N = 2, 4 keep the same per-GPU shard so the curve is weak scaling).
+Independent proofs shard across GPUs with no data-path collective; RCCL only all-gathers the Merkle caps of every proof.
+Every step proves DIFFERENT inputs (fresh 256-bit scalars and a fresh assignment of base points per step and rank).
+After the timed region every proof of the last step is verified with bn254s_verify and one of them is re-proven alone
+(bn254s_prove_g1) and compared word for word, so nothing is timed that was not checked.
+
+`--workload map_to_g2` runs configs[4] instead ("fq_exp STARK + map_to_g2 pipeline, 4096 Fq2 inputs"): the 4096 inputs are
+sharded contiguously over the ranks (64 Fq-exp + 32 G2 proofs in total), caps gathered the same way.
 
 Launch: `python bench.py --gpus N --steps K --warmup W` (N = 1), or for N > 1
 `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P
@@ -14,6 +21,7 @@ Launch: `python bench.py --gpus N --steps K --warmup W` (N = 1), or for N > 1
 from __future__ import annotations
 
 import argparse
+import glob
 import json
 import os
 import sys
@@ -26,16 +34,46 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 INSTANCES_PER_PROOF = 128
-PROOFS_PER_STEP = 8          # 1024 scalar multiplications per GPU per step
 N_ROWS = 1 << 16
 W, A = 781, 456              # trace width, auxiliary polynomials
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s spec
 NTT_BYTES_PER_COL = 40 * N_ROWS   # iNTT r+w 16N, LDE read 8N + write 16N
+SEED0 = 0x706C6F6E6B7932     # SURVEY.md §8(d) "Synthetic inputs"
+MAP_TO_G2_INPUTS = 4096      # configs[4]
+
+
+def proofs_per_gpu(world: int) -> int:
+    """configs[1] on one GPU (1024 scalar-muls = 8 proofs), configs[3]'s shard on several (2048 = 16 proofs per GPU)."""
+    return 8 if world == 1 else 16
 
 
 def shard_range(rank: int, world: int, per_rank: int):
     """Instances [lo, hi) of the global synthetic batch that `rank` proves (weak scaling)."""
     return rank * per_rank, (rank + 1) * per_rank
+
+
+def split_range(rank: int, world: int, total: int):
+    """Contiguous strong-scaling split of `total` units (configs[4]: 4096 inputs): rank r gets [lo, hi)."""
+    base, rem = divmod(total, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def map_to_g2_proof_counts(n_inputs: int):
+    """(Fq-exp proofs, G2 proofs) of n inputs: two Legendre jobs and one cofactor-clearing job per input, 128 per proof."""
+    return (2 * n_inputs + 127) // 128, (n_inputs + 127) // 128
+
+
+def step_inputs(pool, step: int, rank: int):
+    """Inputs of one step: scalars are fresh uniform 256-bit values, base points and offsets a fresh permutation of the
+    rank's pool of synthetic points (seeded by step and rank: every step proves something different)."""
+    xs, offs = pool
+    n = xs.shape[0]
+    rng = np.random.default_rng([SEED0 & 0xFFFFFFFF, 1 + step, rank])
+    scalars = rng.integers(0, 1 << 63, size=(n, 4), dtype=np.uint64) * np.uint64(2) + \
+        rng.integers(0, 2, size=(n, 4), dtype=np.uint64)
+    px, po = rng.permutation(n), rng.permutation(n)
+    return np.ascontiguousarray(scalars), np.ascontiguousarray(xs[px]), np.ascontiguousarray(offs[po])
 
 
 def caps_of(proofs) -> np.ndarray:
@@ -72,40 +110,40 @@ def other_kinds(ctx, synth):
     res = {}
     for name, kind, gen in (("g2_scalar_mul", 1, synth.g2_inputs), ("fq_exp", 2, synth.fq_inputs)):
         try:
-            ins = [np.tile(a, (PROOFS_PER_STEP, 1)) for a in gen(INSTANCES_PER_PROOF)]
+            ins = [np.tile(a, (8, 1)) for a in gen(INSTANCES_PER_PROOF)]
             off = ins[2] if len(ins) > 2 else None
             ctx.prove_batch(kind, ins[0], ins[1], off)
             t0 = time.perf_counter()
             reps = 2
             for _ in range(reps):
-                ctx.prove_batch(kind, ins[0], ins[1], off)
+                proofs = ctx.prove_batch(kind, ins[0], ins[1], off)
             dt = (time.perf_counter() - t0) / reps
-            res[name] = {"proofs_per_s": round(PROOFS_PER_STEP / dt, 2), "ms_per_batch_of_8": round(dt * 1e3, 1),
-                         "instances_per_s": round(PROOFS_PER_STEP * INSTANCES_PER_PROOF / dt, 1)}
+            p = proofs[-1]
+            lo = 128 * (len(proofs) - 1)
+            ctx.verify(kind, p.words, p.degree_bits, ins[0][lo:lo + 128], ins[1][lo:lo + 128],
+                       None if off is None else off[lo:lo + 128], p.outputs)
+            res[name] = {"proofs_per_s": round(8 / dt, 2), "ms_per_batch_of_8": round(dt * 1e3, 1),
+                         "instances_per_s": round(8 * INSTANCES_PER_PROOF / dt, 1), "last_proof_verified": True}
         except Exception as e:
             res[name] = {"error": str(e)}
     return res
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip the G2 / Fq-exp / tall-proof figures reported beside the headline")
-    args = ap.parse_args()
+def latest_profile(pattern: str):
+    """Newest committed profiles/rNN_* file matching the pattern (the PMC passes cannot run inside a timed bench)."""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
+    if not files:
+        return None, None
+    with open(files[-1]) as f:
+        return json.load(f), os.path.relpath(files[-1], ROOT)
 
-    import plonky2_bn254_amd as pk   # first: sets GPU_MAX_HW_QUEUES before the HIP runtime initialises
-    import torch
-    from plonky2_bn254_amd import synth
 
+def init_dist(args):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if rank == 0:
-            print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    if world != args.gpus and rank == 0:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
@@ -113,18 +151,20 @@ def main():
         # BENCH_BACKEND=gloo / BENCH_DEVICE=0 exist only to rehearse the N>1 path on a one-GPU box
         dist_mod.init_process_group(backend=os.environ.get("BENCH_BACKEND", "nccl"), rank=rank, world_size=world)
         dist = dist_mod
-    dev_id = int(os.environ.get("BENCH_DEVICE", local_rank))
-    torch.cuda.set_device(dev_id)
-    device = torch.device("cuda", dev_id)
-    gather_device = device if os.environ.get("BENCH_BACKEND", "nccl") == "nccl" else torch.device("cpu")
-    ctx = pk.Context(dev_id)
+    return rank, local_rank, world, dist
 
-    per_rank = INSTANCES_PER_PROOF * PROOFS_PER_STEP
-    lo, hi = shard_range(rank, world, per_rank)
-    # synthetic inputs: every rank derives its own shard deterministically (seed + rank)
-    s, x, o = synth.g1_inputs(per_rank, seed=0x706C6F6E6B7932 + 1 + rank)
 
-    def step():
+def run_g1(args, pk, torch, synth, ctx, rank, world, dist, device, gather_device):
+    ppg = args.proofs_per_gpu or proofs_per_gpu(world)
+    per_rank = INSTANCES_PER_PROOF * ppg
+    # pool of synthetic points of this rank (x = k1*G, offset = k2*G, python big integers: made once, outside the timing)
+    _, xs, offs = synth.g1_inputs(per_rank, seed=SEED0 + 1 + rank)
+    pool = (xs, offs)
+    n_steps = args.warmup + args.steps
+    inputs = [step_inputs(pool, i, rank) for i in range(n_steps)]
+
+    def step(i):
+        s, x, o = inputs[i]
         proofs = ctx.prove_g1_batch(s, x, o, per_proof=INSTANCES_PER_PROOF)
         caps = caps_of(proofs)
         if dist is not None:
@@ -136,13 +176,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    for i in range(args.warmup):
+        step(i)
     sync()
     t0 = time.perf_counter()
     stage_acc, n_acc = {}, 0
-    for _ in range(args.steps):
-        proofs, caps = step()
+    proofs = caps = None
+    for i in range(args.warmup, n_steps):
+        proofs, caps = step(i)
         for p in proofs:
             for k, v in p.stage_ms.items():
                 stage_acc[k] = stage_acc.get(k, 0.0) + v
@@ -154,74 +195,232 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    if rank == 0:
-        total_proofs = world * PROOFS_PER_STEP * args.steps
-        stage_ms = {k: v / max(n_acc, 1) for k, v in stage_acc.items()}
-        # roofline of the NTT/LDE stage (north-star kernel): HIP-event time of the four NTT launches
-        # of one commitment, measured on the proof's own stream inside the timed region.
-        ntt_ms = stage_ms.get("trace_ntt", 0.0) + stage_ms.get("aux_ntt", 0.0)
-        ntt_bytes = NTT_BYTES_PER_COL * (W + A)
-        achieved = ntt_bytes / (ntt_ms * 1e-3) / 1e9 if ntt_ms > 0 else 0.0
-        # the same stage alone on the GPU (no other stream), after the timed region
-        excl_ms = ctx.bench_ntt(W + A, 5)
-        excl = ntt_bytes / (excl_ms * 1e-3) / 1e9
-        # HBM traffic of the same four launches from the PMC passes (FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc_ntt.md)
-        traffic = None
+    # ---- check what was timed (every rank, after the clock stopped): all proofs of the last step verify, the gathered
+    # caps are the proofs' caps, and one proof equals the single-proof entry point word for word
+    s, x, o = inputs[n_steps - 1]
+    checked = {"verified_proofs": 0, "caps_match": False, "batch_equals_single": False}
+    for j, p in enumerate(proofs):
+        lo = j * INSTANCES_PER_PROOF
+        ctx.verify(0, p.words, p.degree_bits, s[lo:lo + 128], x[lo:lo + 128], o[lo:lo + 128], p.outputs)
+        checked["verified_proofs"] += 1
+    mine = caps[rank] if dist is not None else caps
+    checked["caps_match"] = bool(np.array_equal(mine, caps_of(proofs)))
+    j = (n_steps - 1) % len(proofs)
+    lo = j * INSTANCES_PER_PROOF
+    single = ctx.prove_g1(s[lo:lo + 128], x[lo:lo + 128], o[lo:lo + 128])
+    checked["batch_equals_single"] = bool(np.array_equal(single.words, proofs[j].words))
+    ok = checked["caps_match"] and checked["batch_equals_single"] and checked["verified_proofs"] == len(proofs)
+    if dist is not None:
+        t = torch.tensor([1.0 if ok else 0.0], device=gather_device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        ok = bool(t.item() > 0.5)
+    if not ok:
+        raise SystemExit(f"rank {rank}: timed proofs failed the post-run check: {checked}")
+    if rank != 0:
+        return None
+
+    total_proofs = world * ppg * args.steps
+    stage_ms = {k: v / max(n_acc, 1) for k, v in stage_acc.items()}
+    # roofline of the NTT/LDE stage (north-star kernel): HIP-event time of the NTT launches of the two commitments of a
+    # proof, measured on the proof's own stream inside the timed region.
+    ntt_ms = stage_ms.get("trace_ntt", 0.0) + stage_ms.get("aux_ntt", 0.0)
+    ntt_bytes = NTT_BYTES_PER_COL * (W + A)
+    achieved = ntt_bytes / (ntt_ms * 1e-3) / 1e9 if ntt_ms > 0 else 0.0
+    excl_ms = ctx.bench_ntt(W + A, 5)       # the same stage alone on the GPU (no other stream), after the timed region
+    excl = ntt_bytes / (excl_ms * 1e-3) / 1e9
+    pmc, pmc_src = latest_profile("r*_pmc_ntt.json")
+    traffic = int(pmc["ntt_stage_traffic_bytes_per_1237_cols"]) if pmc else None
+    # integer-ALU roofline of the Poseidon leaf hash (the kernel that bounds proofs/s): wave-level VALU instructions per
+    # second against the issue peak measured by tools/ubench/intops.hip; the instruction count per launch comes from the
+    # committed SQ_INSTS_VALU pass, the duration is measured here with HIP events
+    alu = None
+    try:
+        lh_ms = ctx.bench_leafhash(W, 17, 5)
+        prof, prof_src = latest_profile("r*_alu.json")
+        if prof:
+            insts = float(prof["leaf_hash_valu_wave_insts_per_launch_781x2e17"])
+            peak = float(prof["valu_peak_wave_insts_per_s"])
+            ach = insts / (lh_ms * 1e-3)
+            alu = {"bound": "valu-issue", "kernel": "k_leaf_hash (781 columns x 2^17 leaves = 12.8 M Poseidon permutations)",
+                   "achieved": round(ach / 1e9, 2), "peak": round(peak / 1e9, 2), "unit": "G wave-instr/s",
+                   "frac": round(ach / peak, 4), "ms": round(lh_ms, 4),
+                   "valu_insts_per_permutation": prof.get("valu_insts_per_permutation"),
+                   "permutations_per_s": round((1 << 17) * 98 / (lh_ms * 1e-3) / 1e9, 3), "source": prof_src}
+        else:
+            alu = {"ms": round(lh_ms, 4), "permutations_per_s": round((1 << 17) * 98 / (lh_ms * 1e-3) / 1e9, 3)}
+    except Exception as e:
+        alu = {"error": str(e)}
+    # the same 1024 scalar multiplications as ONE tall proof (N = 2^19), the shape Bn254Hook::constrain produces for a
+    # circuit with 1024 calls; reported next to the headline, not part of `value`
+    tall = None
+    if world == 1 and not args.no_extras:
         try:
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_ntt.json")) as f:
-                traffic = int(json.load(f)["ntt_stage_traffic_bytes_per_1237_cols"])
-        except Exception:
-            pass
-        # the same 1024 scalar multiplications as ONE tall proof (N = 2^19), the shape Bn254Hook::constrain produces for a
-        # circuit with 1024 calls; reported next to the headline, not part of `value`
-        tall = None
-        try:
-            if args.no_extras:
-                raise RuntimeError("skipped (--no-extras)")
-            ctx.prove_g1(s, x, o)
+            s8, x8, o8 = s[:1024], x[:1024], o[:1024]
+            ctx.prove_g1(s8, x8, o8)
             tt0 = time.perf_counter()
-            ctx.prove_g1(s, x, o)
+            tp = ctx.prove_g1(s8, x8, o8)
             tdt = time.perf_counter() - tt0
-            tall = {"rows_log2": 19, "ms_per_proof": round(tdt * 1e3, 2), "scalar_muls_per_s": round(per_rank / tdt, 1)}
+            ctx.verify(0, tp.words, tp.degree_bits, s8, x8, o8, tp.outputs)
+            tall = {"rows_log2": tp.degree_bits, "ms_per_proof": round(tdt * 1e3, 2),
+                    "scalar_muls_per_s": round(1024 / tdt, 1), "verified": True}
         except Exception as e:
             tall = {"error": str(e)}
-        out = {
-            "metric": "G1 scalar-mul STARK proofs/sec (256-bit scalars)",
-            "value": round(total_proofs / dt, 3),
-            "unit": "proofs/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 3),
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "u64 (Goldilocks p = 2^64-2^32+1; BN254 Fq as 10x26-bit Montgomery limbs)",
-            "data": "synthetic",
-            "config": {"workload": "configs[1]: batch of 1024 G1 scalar-muls per GPU per step = 8 proofs x 128 instances, "
-                                   "2^16 rows, W=781, standard_fast_config",
-                       "proofs_per_step_per_gpu": PROOFS_PER_STEP, "instances_per_proof": INSTANCES_PER_PROOF,
-                       "parallelism": f"{world} x independent proofs, RCCL all-gather of Merkle caps"},
-            "scalar_muls_per_s": round(total_proofs * INSTANCES_PER_PROOF / dt, 1),
-            "stage_ms_per_proof": {k: round(v, 3) for k, v in stage_ms.items()},
-            "one_tall_proof_of_1024": tall,
-            "roofline": {"bound": "hbm", "kernel": "ntt_lde stage = k_ntt_pass1 (iNTT) + k_ntt_intt2_lde1 (fused iNTT pass 2 / pass 1 of "
-                                                   "both cosets) + k_ntt_pass2 x {coset g, coset g*w_2N} over the 781 trace + 456 aux "
-                                                   "columns of one proof",
-                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "algorithmic_bytes": ntt_bytes, "ms": round(ntt_ms, 4),
-                         "exclusive": {"achieved": round(excl, 1), "frac": round(excl / HBM_PEAK_GBS, 4),
-                                       "ms": round(excl_ms, 4),
-                                       "note": "same four launches with no other stream on the GPU (bn254s_bench_ntt)"}},
-        }
-        if world == 1 and not args.no_extras:
-            out["other_kinds"] = other_kinds(ctx, synth)
-        if world == 1 and not args.no_cpu_baseline:
-            try:
-                out["cpu_baseline"] = cpu_baseline()
-            except Exception as e:  # the bench line must still be produced
-                out["cpu_baseline"] = {"value": None, "unit": "proofs/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
+    cfg = "configs[1]: batch of 1024 G1 scalar-muls on 1 GPU per step = 8 proofs x 128 instances" if world == 1 and ppg == 8 else \
+        (f"configs[3] shard: {per_rank} G1 scalar-muls = {ppg} proofs x 128 instances per GPU per step "
+         f"({world * per_rank} per step over {world} GPUs" + ("; N = 8 is the 16384 of configs[3])" if ppg == 16 else ")"))
+    out = {
+        "metric": "G1 scalar-mul STARK proofs/sec (256-bit scalars)",
+        "value": round(total_proofs / dt, 3),
+        "unit": "proofs/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 3),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u64 (Goldilocks p = 2^64-2^32+1; BN254 Fq as 10x26-bit Montgomery limbs)",
+        "data": "synthetic (fresh random 256-bit scalars and point assignment every step)",
+        "config": {"workload": cfg + ", 2^16 rows, W=781, standard_fast_config",
+                   "proofs_per_step_per_gpu": ppg, "instances_per_proof": INSTANCES_PER_PROOF,
+                   "parallelism": "1 GPU, no collective" if world == 1 else
+                                  f"{world} ranks x independent proofs, one RCCL all-gather of the Merkle caps per step"},
+        "checked": checked,
+        "scalar_muls_per_s": round(total_proofs * INSTANCES_PER_PROOF / dt, 1),
+        "stage_ms_per_proof": {k: round(v, 3) for k, v in stage_ms.items()},
+        "one_tall_proof_of_1024": tall,
+        "roofline": {"bound": "hbm", "kernel": "ntt_lde stage = iNTT + both coset NTTs (k_ntt_* launches) over the 781 trace "
+                                               "+ 456 aux columns of one proof",
+                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                     "traffic_source": (f"static: FETCH_SIZE/WRITE_SIZE PMC passes of the same launches, {pmc_src}"
+                                        if pmc_src else None),
+                     "algorithmic_bytes": ntt_bytes, "ms": round(ntt_ms, 4),
+                     "exclusive": {"achieved": round(excl, 1), "frac": round(excl / HBM_PEAK_GBS, 4),
+                                   "ms": round(excl_ms, 4),
+                                   "note": "same launches with no other stream on the GPU (bn254s_bench_ntt)"}},
+        "roofline_alu": alu,
+    }
+    if world == 1 and not args.no_extras:
+        out["other_kinds"] = other_kinds(ctx, synth)
+    if world == 1 and not args.no_cpu_baseline:
+        try:
+            out["cpu_baseline"] = cpu_baseline()
+        except Exception as e:  # the bench line must still be produced
+            out["cpu_baseline"] = {"value": None, "unit": "proofs/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
+    return out
+
+
+def map_to_g2_inputs(lo: int, hi: int):
+    """Inputs [lo, hi) of the global 4096-input batch of configs[4]: uniform Fq2 elements u (xoshiro stream of
+    tools/map_to_g2_ref.inputs) and non-infinity G2 offsets (128 distinct synthetic points, tiled by global index)."""
+    from plonky2_bn254_amd import synth
+    from tools import map_to_g2_ref as m2g
+    us = m2g.inputs(hi)[lo:hi]
+    u = np.array([synth._to_words(a[0]) + synth._to_words(a[1]) for a in us], dtype=np.uint64).reshape(hi - lo, 8)
+    _, _, base_off = synth.g2_inputs(128, seed=SEED0 + 5)
+    off = base_off[np.arange(lo, hi) % 128].copy()
+    return u, off
+
+
+def run_map_to_g2(args, pk, torch, synth, ctx, rank, world, dist, device, gather_device):
+    total = args.inputs
+    lo, hi = split_range(rank, world, total)
+    u, off = map_to_g2_inputs(lo, hi)
+    n_steps = args.warmup + args.steps
+
+    def step(i):
+        # a different slice order every step: rotate the rank's inputs (same multiset, different proofs)
+        r = i % max(hi - lo, 1)
+        uu, oo = np.roll(u, r, axis=0), np.roll(off, r, axis=0)
+        res = ctx.map_to_g2(np.ascontiguousarray(uu), np.ascontiguousarray(oo))
+        caps = caps_of(res[3] + res[4])
+        if dist is not None:
+            # ranks may hold different proof counts when world does not divide the inputs: pad to the maximum
+            n_max = sum(map_to_g2_proof_counts(split_range(0, world, total)[1]))
+            pad = np.zeros((n_max, 192), np.uint64)
+            pad[:caps.shape[0]] = caps
+            caps = gather_caps(pad, dist, gather_device)
+        return (uu, oo) + tuple(res), caps
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    sync()
+    t0 = time.perf_counter()
+    for i in range(args.warmup, n_steps):
+        last, caps = step(i)
+    sync()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=gather_device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    # check the last step: every proof verifies against the job arrays the library returned
+    uu, oo, pts, fq_jobs, g2_jobs, pf, pg = last
+    fs, fx = np.ascontiguousarray(fq_jobs[:, :4]), np.ascontiguousarray(fq_jobs[:, 4:])
+    gs, gx = np.ascontiguousarray(g2_jobs[:, :4]), np.ascontiguousarray(g2_jobs[:, 4:])
+    for i, p in enumerate(pf):
+        a = 128 * i
+        ctx.verify(2, p.words, p.degree_bits, fs[a:a + 128], fx[a:a + 128], None, p.outputs)
+    for i, p in enumerate(pg):
+        a = 128 * i
+        ctx.verify(1, p.words, p.degree_bits, gs[a:a + 128], gx[a:a + 128], oo[a:a + 128], p.outputs)
+    if rank != 0:
+        return None
+    n_fq, n_g2 = 0, 0
+    for r in range(world):
+        a, b = split_range(r, world, total)
+        f, g = map_to_g2_proof_counts(b - a)
+        n_fq, n_g2 = n_fq + f, n_g2 + g
+    return {
+        "metric": "map_to_g2 inputs/sec (fq_exp STARK + G2 scalar-mul STARK pipeline)",
+        "value": round(total * args.steps / dt, 2),
+        "unit": "inputs/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 3),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "u64 (Goldilocks) / BN254 Fq as 10x26-bit Montgomery limbs",
+        "data": "synthetic",
+        "config": {"workload": f"configs[4]: fq_exp STARK + map_to_g2 pipeline, {total} Fq2 inputs = {n_fq} Fq-exp proofs + "
+                               f"{n_g2} G2 proofs of 128 instances, inputs sharded contiguously over {world} GPU(s)",
+                   "parallelism": "1 GPU, no collective" if world == 1 else
+                                  f"{world} ranks, one RCCL all-gather of the Merkle caps per step"},
+        "proofs_per_s": round((n_fq + n_g2) * args.steps / dt, 2),
+        "checked": {"verified_proofs_rank0_last_step": len(pf) + len(pg)},
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", choices=("g1", "map_to_g2"), default="g1",
+                    help="g1 = the headline metric (configs[1] / configs[3]); map_to_g2 = configs[4]")
+    ap.add_argument("--proofs-per-gpu", type=int, default=0, help="override the per-GPU batch of the g1 workload")
+    ap.add_argument("--inputs", type=int, default=MAP_TO_G2_INPUTS, help="map_to_g2 workload: total Fq2 inputs per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the G2 / Fq-exp / tall-proof figures reported beside the headline")
+    args = ap.parse_args()
+
+    import plonky2_bn254_amd as pk   # first: sets GPU_MAX_HW_QUEUES before the HIP runtime initialises
+    import torch
+    from plonky2_bn254_amd import synth
+
+    rank, local_rank, world, dist = init_dist(args)
+    dev_id = int(os.environ.get("BENCH_DEVICE", local_rank))
+    torch.cuda.set_device(dev_id)
+    device = torch.device("cuda", dev_id)
+    gather_device = device if os.environ.get("BENCH_BACKEND", "nccl") == "nccl" else torch.device("cpu")
+    ctx = pk.Context(dev_id)
+    fn = run_g1 if args.workload == "g1" else run_map_to_g2
+    out = fn(args, pk, torch, synth, ctx, rank, world, dist, device, gather_device)
+    if rank == 0:
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

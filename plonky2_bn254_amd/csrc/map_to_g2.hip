@@ -8,7 +8,7 @@
 //   [n G2 proofs of cofactor * (x, y) + offset]
 //   k_m2g_finish:     output - offset                                                (hash_to_g2.rs:200-205)
 // Square roots follow ark-ff 0.4 (Fq: a^((p+1)/4); Fq2: the "complex method" of QuadExtField::sqrt), like the Python
-// front-end plonky2_bn254_amd/map_to_g2.py, which is the parity reference of tests/test_map_to_g2.py.
+// front-end tools/map_to_g2_ref.py, which is the parity reference of tests/test_map_to_g2.py.
 #include <cstring>
 #include <string>
 #include <vector>

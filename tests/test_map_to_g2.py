@@ -3,7 +3,7 @@ fq_exp proofs -> Legendre results -> G2 cofactor-clearing proofs on the GPU (src
 import numpy as np
 import pytest
 
-from plonky2_bn254_amd import map_to_g2 as m2g
+from tools import map_to_g2_ref as m2g
 from plonky2_bn254_amd import synth
 
 

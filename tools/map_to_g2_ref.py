@@ -20,8 +20,8 @@ from __future__ import annotations
 
 import numpy as np
 
-from . import synth
-from .synth import P, f2_add, f2_inv, f2_mul, f2_sub
+from plonky2_bn254_amd import synth
+from plonky2_bn254_amd.synth import P, f2_add, f2_inv, f2_mul, f2_sub
 
 COFACTOR = 21888242871839275222246405745257275088844257914179612981679871602714643921549  # hash_to_g2.rs:69-71
 LEGENDRE_EXP = (P - 1) // 2
@@ -172,7 +172,7 @@ _MDS = [17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20]
 def _round_constants():
     import os
     import re
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "poseidon_constants.inc")
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "plonky2_bn254_amd", "csrc", "poseidon_constants.inc")
     return [int(h, 16) for h in re.findall(r"0x([0-9a-fA-F]{16})ULL", open(path).read())]
 
 

@@ -9,7 +9,7 @@ import numpy as np
 
 sys.path.insert(0, __file__.rsplit("/tools/", 1)[0])
 import plonky2_bn254_amd as pk
-from plonky2_bn254_amd import map_to_g2 as m2g
+from tools import map_to_g2_ref as m2g
 from plonky2_bn254_amd import synth
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
