@@ -210,7 +210,7 @@ int bn254s_bench_leafhash(bn254s_ctx* c, size_t ncols, int log_leaves, int iters
   return BN254S_OK;
 }
 
-__global__ void k_poseidon_states(u64* st, size_t n) {
+__global__ __launch_bounds__(256) void k_poseidon_states(u64* st, size_t n) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   u64 s[12];

@@ -7,33 +7,50 @@
 #include "merkle.h"
 #include "poseidon_dev.h"
 
-__global__ __launch_bounds__(256) void k_leaf_hash(const u64* __restrict__ data, size_t leaf_stride, size_t elem_stride,
-                                                   int leaf_len, size_t n_leaves, u64* __restrict__ digests) {
+// Element c of leaf j sits at data[c * elem_stride + j * leaf_stride]: the column part of the address is wave-uniform (scalar
+// registers), the lane part one 32-bit byte offset.  The whole hash_no_pad loop (loads of the next eight columns while the
+// current eight are being absorbed, round 0's constants, permutation) is the hand-scheduled statement POSEIDON_ASM_SPONGE,
+// which keeps the sponge state in its own registers from the first column to the last.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_leaf_hash(
+    const u64* __restrict__ data, size_t leaf_stride, size_t elem_stride, int leaf_len, size_t n_leaves, u64* __restrict__ digests) {
+#if defined(__HIP_DEVICE_COMPILE__)  // (the host pass only needs the signature)
   size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n_leaves) return;
-  const u64* p = data + j * leaf_stride;
-  u64 s[12];
-#pragma unroll
-  for (int i = 0; i < 12; i++) s[i] = 0;
+  const u32 lane_off = (u32)(j * leaf_stride);  // host side guarantees n_leaves * leaf_stride < 2^29
+  u64 s[4] = {0, 0, 0, 0};
   if (leaf_len <= 4) {
-    for (int i = 0; i < leaf_len; i++) s[i] = p[(size_t)i * elem_stride];
+    for (int i = 0; i < leaf_len; i++) s[i] = data[(size_t)i * elem_stride + lane_off];
   } else {
-    int c = 0;
-    for (; c + 8 <= leaf_len; c += 8) {
+#if defined(BN254S_POSEIDON_PLAIN)
+    u64 t[12];
 #pragma unroll
-      for (int i = 0; i < 8; i++) s[i] = p[(size_t)(c + i) * elem_stride];
-      poseidon_permute(s);
-    }
-    if (c < leaf_len) {
+    for (int i = 0; i < 12; i++) t[i] = 0;
+#pragma unroll 1
+    for (int c = 0; c < leaf_len; c += 8) {
+      const u64* col = data + (size_t)c * elem_stride;
 #pragma unroll
       for (int i = 0; i < 8; i++)
-        if (c + i < leaf_len) s[i] = p[(size_t)(c + i) * elem_stride];
-      poseidon_permute(s);
+        if (c + i < leaf_len) t[i] = (col + (size_t)i * elem_stride)[lane_off];
+      poseidon_permute_plain(t);
     }
+#pragma unroll
+    for (int i = 0; i < 4; i++) s[i] = t[i];
+#else
+    const u32 byte_off = lane_off * 8u;
+    const u64 stride_bytes = (u64)elem_stride * 8u;
+    asm volatile(POSEIDON_ASM_SPONGE
+                 : [o0] "=&v"(s[0]), [o1] "=&v"(s[1]), [o2] "=&v"(s[2]), [o3] "=&v"(s[3])
+                 : [col] "s"(data), [off] "v"(byte_off), [stride] "s"(stride_bytes), [len] "s"(leaf_len),
+                   [rc] "s"(POSEIDON_RC_DEV), [tab] "s"(POSEIDON_INIT_DEV)
+                 : POSEIDON_ASM_CLOBBERS, POSEIDON_ASM_SPONGE_CLOBBERS, "memory");
+#pragma unroll
+    for (int i = 0; i < 4; i++) s[i] = s[i] >= GL_P ? s[i] - GL_P : s[i];
+#endif
   }
   ulonglong2* o = reinterpret_cast<ulonglong2*>(digests + 4 * j);
   o[0] = make_ulonglong2(s[0], s[1]);
   o[1] = make_ulonglong2(s[2], s[3]);
+#endif
 }
 
 __global__ __launch_bounds__(256) void k_merkle_level(const u64* __restrict__ in, u64* __restrict__ out, size_t n_out) {

@@ -1,0 +1,757 @@
+#!/usr/bin/env python3
+"""Generator of the hand-scheduled Poseidon-Goldilocks permutation for gfx950 (csrc/poseidon_asm.inc).
+
+The compiler's output for the permutation spends a third of its issue slots on register-pair moves, carry chains
+(v_sub_co / v_subb_co cost 2.6 simple-op slots each on this chip) and compare/select fix-ups.  This
+script emits the permutation as ONE inline-asm statement with its own register allocation and interleaving:
+
+  * lanes are pairs of 32-bit digits (x = x0 + x1 phi, phi = 2^32, phi^2 = phi - 1 mod p), any representative < 2^64;
+  * a product is 4 v_mad_u64_u32 + 3 moves/selects (the carry of the third product goes to an SGPR pair and is re-injected
+    through the high half of the last addend); its reduction is w0 + w1 phi + w2 (phi - 1) - w3 with ONE multiply-add, one
+    64-bit subtraction, three scalar mask operations, three selects and one 64-bit add - exact for every input;
+  * the MDS layer is 290 v_mad_u64_u32 into 24 64-bit digit sums whose initial values are the next round's constants (no
+    constant is ever "added"), an output al + ah phi is folded exactly with one multiply-add (al + ah1 (phi - 1)), one add
+    with carry-out, one select and one 64-bit add;
+  * the S-boxes of a full round run three at a time, the S-box of a partial round is interleaved with the 176
+    multiply-adds of the layer that do not depend on it;
+  * every value inside the statement is "any representative below 2^64"; nothing is approximate and there is no fall-back.
+
+Two statements are generated from the same round code: POSEIDON_ASM_PERMUTE (one permutation of twelve 64-bit operands, round
+0's constants already added) and POSEIDON_ASM_SPONGE (the whole hash_no_pad loop of the Merkle leaf kernel: loads of the
+next eight columns, round 0's constants, permutation; the state never leaves the register block).
+
+The instruction lists are first executed by the interpreter below (one lane, Python integers) on the known-answer vectors
+and random inputs and compared with the textbook permutation; then printed.
+usage: python tools/gen_poseidon_asm.py [out_dir = plonky2_bn254_amd/csrc]
+"""
+import os
+import random
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from derive_poseidon_constants import KATS, MDS_CIRC, P, permute, round_constants  # noqa: E402
+
+M32 = 0xFFFFFFFF
+M64 = (1 << 64) - 1
+
+# ---- register map (physical registers named inside the asm string; all of them are declared clobbered) ----------------
+VB = 26            # first VGPR of the block; the block ends at v125 (128 registers = four waves per SIMD)
+A0 = VB            # bank A: the state, lane i = v[A0+2i : A0+2i+1]
+S0 = VB + 24       # bank S: S-box outputs of a full round / the second state bank of the partial rounds
+TMP = VB + 48      # S-box stream temporaries / MDS digit sums
+N_STREAMS = 3
+STREAM_REGS = 16
+E0 = TMP + N_STREAMS * STREAM_REGS     # two pairs (e, 0): the "+ (2^32 - 1) if carry" addends
+V_END = E0 + 4
+A = [(A0 + 2 * i, A0 + 2 * i + 1) for i in range(12)]
+S = [(S0 + 2 * i, S0 + 2 * i + 1) for i in range(12)]
+LD0 = 10           # v10..v25: staging of the next chunk's eight loads (sponge statement only)
+SB_LOOP = 24       # s[24:29]: column pointer, column stride in bytes, element index, leaf length (sponge statement)
+SB_MASK = (30, 34, 22)    # s[30:31], s[34:35], s[22:23]: one scratch mask pair per stream (s32, s33 stay untouched)
+SB_CARRY = 36      # s[36:47]: two carry pairs per stream; the folds use the first four pairs
+SB_CONST = 48      # s[48:95]: the 48 dwords of one round of initial digit sums (or round 0's 12 constants)
+S_PTR = 96         # s[96:97]: running pointer into the table
+S_CNT = 98
+S_HALF = 99
+ROUND_BYTES = 192
+
+
+def init_table(rc):
+    """INIT[r][j]: what the MDS layer of round r adds to output j = the constants of round r's own partial-round lanes pushed
+    through the layer + the pre-S-box constant of round r + 1 (all 12 lanes before a full round, lane 0 before a partial
+    one).  Round 0's own pre-S-box constants are added up front.  One extra all-zero round pads the prefetch."""
+    full = lambda r: r < 4 or r >= 26
+    tab = []
+    for r in range(30):
+        row = []
+        for j in range(12):
+            k = 0
+            if not full(r):
+                k += sum(MDS_CIRC[(i - j) % 12] * rc[12 * r + i] for i in range(1, 12))
+            if r + 1 < 30:
+                if full(r + 1) or j == 0:
+                    k += rc[12 * (r + 1) + j]
+            row.append(k % P)
+        tab.append(row)
+    tab.append([0] * 12)
+    return tab
+
+
+def table_dwords(tab):
+    out = []
+    for row in tab:
+        for k in row:
+            out += [k & M32, 0, k >> 32, 0]
+    return out
+
+
+# ---- instruction emission ---------------------------------------------------------------------------------------------
+class Prog:
+    def __init__(self):
+        self.ins = []      # tuples (op, args...)
+
+    def emit(self, *t):
+        self.ins.append(t)
+
+
+def v(i):
+    return ("v", i)
+
+
+def vp(i):
+    assert i % 2 == 0, i
+    return ("vp", i)
+
+
+def sp(i):
+    assert i % 2 == 0
+    return ("sp", i)
+
+
+def interleave(p, tasks):
+    for t in round_robin(tasks):
+        p.emit(*t)
+
+
+def round_robin(tasks):
+    tasks = list(tasks)
+    while tasks:
+        for t in list(tasks):
+            try:
+                yield next(t)
+            except StopIteration:
+                tasks.remove(t)
+
+
+def mul_task(a, b, dst, t, cA, cB, cT):
+    """(a0,a1) x (b0,b1) -> dst pair, exact, any representative below 2^64.  a, b: (lo reg, hi reg); t: base of 10 stream
+    temporaries with v[t+3] == 0 throughout; cA, cB, cT: three SGPR pairs of the stream.  Yields instructions one at a time so
+    that several products can be interleaved.
+    product (w0..w3 32-bit words) = P0 | R0 | S0 | S1 from four multiply-adds; reduction X = w0 + w1 phi + w2 (phi - 1) - w3:
+    t = V + w2 (2^32 - 1) with carry c, t' = t - w3 with borrow b (two carry instructions), then + (c - b)(2^32 - 1):
+    after a carry t < 2^64 - 2^33 and after a borrow t' > 2^64 - 2^32, so neither correction wraps again."""
+    a0, a1 = a
+    b0, b1 = b
+    Pp, T, Q, R, Sx = t, t + 2, t + 4, t + 6, t + 8
+    yield ("mad", vp(Pp), "vcc", v(a0), v(b0), 0)
+    yield ("mov", v(T), v(Pp + 1))
+    yield ("mad", vp(Q), "vcc", v(a0), v(b1), vp(T))
+    yield ("mad", vp(R), sp(cA), v(a1), v(b0), vp(Q))
+    yield ("mov", v(Q), v(R + 1))                      # U.lo = R1
+    yield ("mov", v(Pp + 1), v(R))                     # V = (w0, w1)
+    yield ("cnd", v(Q + 1), 0, 1, sp(cA))              # U.hi = carry of the third product
+    yield ("mad", vp(Sx), "vcc", v(a1), v(b1), vp(Q))  # S = (w2, w3)
+    yield ("mad", vp(R), sp(cB), v(Sx), -1, vp(Pp))    # t = V + w2 * (2^32 - 1), carry c -> cB
+    yield ("subco", v(R), sp(cA), v(R), v(Sx + 1))     # t' = t - w3 ...
+    yield ("subbco", v(R + 1), sp(cA), v(R + 1), 0, sp(cA))   # ... borrow b -> cA
+    yield ("s_xor", sp(cT), sp(cA), sp(cB))
+    yield ("s_and", sp(cB), sp(cT), sp(cB))            # c and not b: + (2^32 - 1)
+    yield ("s_and", sp(cA), sp(cT), sp(cA))            # b and not c: - (2^32 - 1) = + (1, 0xFFFFFFFF)
+    yield ("cnd", v(Q), 0, -1, sp(cB))
+    yield ("cnd", v(Q + 1), 0, -1, sp(cA))
+    yield ("cnd", v(Q), v(Q), 1, sp(cA))
+    yield ("add64", vp(dst), vp(R), vp(Q))
+
+
+def sbox_task(x, dst, stream):
+    """x^7 of the lane held in the registers x = (lo, hi) -> the pair dst (dst may be x's own pair)."""
+    t = TMP + stream * STREAM_REGS
+    X2, X3, X4 = t + 10, t + 12, t + 14
+    cA, cB, cT = SB_CARRY + 4 * stream, SB_CARRY + 4 * stream + 2, SB_MASK[stream]
+    yield from mul_task(x, x, X2, t, cA, cB, cT)
+    yield from mul_task((X2, X2 + 1), (X2, X2 + 1), X4, t, cA, cB, cT)
+    yield from mul_task((X2, X2 + 1), x, X3, t, cA, cB, cT)
+    yield from mul_task((X3, X3 + 1), (X4, X4 + 1), dst, t, cA, cB, cT)
+
+
+def mds_terms(j, lane0_last):
+    """(coefficient, source lane) of output j, optionally with the lane-0 terms at the end."""
+    terms = [(MDS_CIRC[i], (i + j) % 12) for i in range(12)]
+    if j == 0:
+        terms.append((8, 0))
+    if lane0_last:
+        terms = [t for t in terms if t[1] != 0] + [t for t in terms if t[1] == 0]
+    return terms
+
+
+def mds_group_tasks(src, g, lane0_last, split_at_lane0=False, acc0=TMP):
+    """Accumulation of outputs 4g..4g+3: eight independent chains (al, ah of four outputs) as eight tasks.  With
+    split_at_lane0 every chain is returned as (before, after) the first lane-0 term."""
+    tasks = []
+    for q in range(4):
+        j = 4 * g + q
+        for h in range(2):
+            acc = acc0 + 4 * q + 2 * h
+            init = SB_CONST + 4 * j + 2 * h
+
+            def chain(j=j, h=h, acc=acc, init=init, part=None):
+                first = True
+                for c, lane in mds_terms(j, lane0_last):
+                    is0 = lane == 0
+                    if part == "before" and is0:
+                        return
+                    if part == "after" and not is0:
+                        first = False
+                        continue
+                    yield ("mad", vp(acc), "vcc", v(src[lane][h]), c, sp(init) if first else vp(acc))
+                    first = False
+            if split_at_lane0:
+                tasks.append((chain(part="before"), chain(part="after")))
+            else:
+                tasks.append(chain())
+    return tasks
+
+
+def fold_group(p, dst, g, acc0=TMP):
+    """out_j = al + ah phi exactly, any representative: u = al + ah1 (phi - 1) (no carry: both below 2^42);
+    (u1 + ah0) mod 2^32 with its carry c; + c (2^32 - 1) (cannot wrap: after a carry the high digit is below 2^10)."""
+    q_al = [acc0 + 4 * q for q in range(4)]
+    q_ah = [acc0 + 4 * q + 2 for q in range(4)]
+    for q in range(4):
+        p.emit("mad", vp(q_al[q]), "vcc", v(q_ah[q] + 1), -1, vp(q_al[q]))
+    for q in range(4):
+        p.emit("addco", v(q_al[q] + 1), sp(SB_CARRY + 2 * q), v(q_al[q] + 1), v(q_ah[q]))
+    for half in (0, 2):
+        for k in (0, 1):
+            p.emit("cnd", v(E0 + 2 * k), 0, -1, sp(SB_CARRY + 2 * (half + k)))
+        for k in (0, 1):
+            p.emit("add64", vp(dst[4 * g + half + k][0]), vp(q_al[half + k]), vp(E0 + 2 * k))
+
+
+def rezero_stream_temps(p, streams):
+    """The MDS digit sums overlay the S-box temporaries: restore the zero high halves of the T pairs."""
+    for s in streams:
+        p.emit("mov", v(TMP + s * STREAM_REGS + 3), 0)
+
+
+def prefetch_next(p):
+    p.emit("s_add_ptr", ROUND_BYTES)
+    for k in range(3):
+        p.emit("s_load16", SB_CONST + 16 * k, 64 * k)
+
+
+EXPERIMENT = os.environ.get("POSEIDON_GEN_EXPERIMENT", "")     # timing experiments only (tools/ubench): wrong results
+
+
+def full_round(p):
+    """A -> S-boxes -> S -> MDS -> A."""
+    rezero_stream_temps(p, range(N_STREAMS))
+    if "nosbox" not in EXPERIMENT:
+        for k in range(0, 12, N_STREAMS):
+            interleave(p, [sbox_task(A[lane], S[lane][0], s) for s, lane in enumerate(range(k, min(12, k + N_STREAMS)))])
+    p.emit("s_waitcnt")
+    if "nomds" in EXPERIMENT:
+        prefetch_next(p)
+        return
+    for g in range(3):
+        interleave(p, mds_group_tasks(S, g, False))
+        if g == 2:
+            prefetch_next(p)          # every initial digit sum of this round has been consumed
+        if "nofold" not in EXPERIMENT:
+            fold_group(p, A, g)
+
+
+def partial_round(p, src, dst, ratio=3):
+    """The single S-box (lane 0, in the last stream's registers, result in place) is interleaved with the part of output
+    groups 0 and 1 that does not depend on lane 0 (176 multiply-adds), `ratio` of them per S-box instruction; the lane-0
+    terms, the folds and group 2 follow."""
+    assert N_STREAMS * STREAM_REGS >= 32 + STREAM_REGS
+    p.emit("s_waitcnt")
+    head = sbox_task(src[0], src[0][0], N_STREAMS - 1)
+    acc1 = TMP + 16
+    pairs = mds_group_tasks(src, 0, True, split_at_lane0=True) + mds_group_tasks(src, 1, True, split_at_lane0=True, acc0=acc1)
+    body = round_robin([b for b, _ in pairs])
+    head_done = body_done = False
+    while not (head_done and body_done):
+        if not head_done:
+            try:
+                p.emit(*next(head))
+            except StopIteration:
+                head_done = True
+        for _ in range(ratio):
+            if not body_done:
+                try:
+                    p.emit(*next(body))
+                except StopIteration:
+                    body_done = True
+    interleave(p, [a for _, a in pairs])
+    fold_group(p, dst, 0)
+    fold_group(p, dst, 1, acc0=acc1)
+    interleave(p, mds_group_tasks(src, 2, False))
+    prefetch_next(p)
+    fold_group(p, dst, 2)
+
+
+def permutation_body(p, tag=""):
+    """30 rounds on bank A (round 0's constants already added); the table pointer S_PTR must point at INIT[0]."""
+    p.emit("s_mov", S_HALF, 0)
+    for k in range(3):
+        p.emit("s_load16", SB_CONST + 16 * k, 64 * k)
+    p.emit("label", "half" + tag)
+    p.emit("s_mov", S_CNT, 4)
+    p.emit("label", "full" + tag)
+    full_round(p)
+    p.emit("loop", S_CNT, "full" + tag)
+    p.emit("s_branch_if_ne0", S_HALF, "done" + tag)
+    rezero_stream_temps(p, [N_STREAMS - 1])
+    p.emit("s_mov", S_CNT, 11)
+    p.emit("label", "part" + tag)
+    partial_round(p, A, S)
+    partial_round(p, S, A)
+    p.emit("loop", S_CNT, "part" + tag)
+    p.emit("s_mov", S_HALF, 1)
+    p.emit("s_branch", "half" + tag)
+    p.emit("label", "done" + tag)
+    p.emit("s_waitcnt")                    # the last prefetch (padding round) must land before the registers are reused
+
+
+def build_permute():
+    p = Prog()
+    p.emit("copy_in")                      # v_mov_b64 of the 12 operands into bank A, (e, 0) pairs
+    p.emit("s_ptr", "tab")
+    permutation_body(p)
+    p.emit("copy_out")
+    return p
+
+
+def build_sponge():
+    """hash_no_pad over leaf_len elements (leaf_len > 0) from the all-zero state: per chunk of <= 8 elements overwrite lanes
+    0.., add round 0's constants (lazily: any representative), permute.  The loads of chunk c + 1 are issued before the
+    permutation of chunk c into staging registers."""
+    p = Prog()
+    p.emit("zero_in")
+    p.emit("sponge_init")                  # s[24:25] = column pointer, s[26:27] = stride, s28 = 0, s29 = leaf_len
+    p.emit("s_rem")
+    for i in range(8):
+        p.emit("gload", vp(LD0 + 2 * i), i, 0)     # if (i < len) LD[i] = *(col + lane offset); col += stride
+    p.emit("label", "chunk")
+    p.emit("s_rem")                        # S_CNT = len - idx
+    p.emit("s_waitcnt_all")
+    for i in range(8):
+        p.emit("take", vp(A[i][0]), vp(LD0 + 2 * i), i)   # if (idx + i < len) A[i] = LD[i]
+    for i in range(8):
+        p.emit("gload", vp(LD0 + 2 * i), i, 8)     # if (idx + 8 + i < len) LD[i] = next element
+    p.emit("s_ptr", "rc")
+    for k in range(3):
+        p.emit("s_load8", SB_CONST + 8 * k, 32 * k)
+    p.emit("s_waitcnt")
+    # lazy addition of round 0's constants: s = a + rc; wrapped iff s < rc; then + (2^32 - 1)
+    for base in range(0, 12, 2):
+        for k in (0, 1):
+            i = base + k
+            p.emit("add64", vp(A[i][0]), vp(A[i][0]), sp(SB_CONST + 2 * i))
+        for k in (0, 1):
+            i = base + k
+            p.emit("cmplt64", sp(SB_CARRY + 2 * k), vp(A[i][0]), sp(SB_CONST + 2 * i))
+        p.emit("s_nop", 0)
+        for k in (0, 1):
+            p.emit("cnd", v(E0 + 2 * k), 0, -1, sp(SB_CARRY + 2 * k))
+        for k in (0, 1):
+            i = base + k
+            p.emit("add64", vp(A[i][0]), vp(A[i][0]), vp(E0 + 2 * k))
+    p.emit("s_ptr", "tab")
+    permutation_body(p)
+    p.emit("chunk_loop", "chunk")          # idx += 8; if (idx < len) goto chunk
+    p.emit("digest_out")
+    return p
+
+
+# ---- hazards: a VALU instruction may read an SGPR written by a VALU instruction only 2 wait states later --------------------
+VALU = ("mad", "mov", "cnd", "sub", "add64", "addco", "subco", "subbco", "cmplt64")
+
+
+def sgpr_reads(t):
+    srcs = t[3:] if t[0] in ("mad", "addco", "subco", "subbco") else t[2:]
+    return [a[1] for a in srcs if isinstance(a, tuple) and a[0] == "sp"]
+
+
+def sgpr_write(t):
+    if t[0] in ("mad", "addco", "subco", "subbco") and isinstance(t[2], tuple):
+        return t[2][1]
+    if t[0] == "cmplt64":
+        return t[1][1]
+    return None
+
+
+def pad_hazards(ins):
+    out = []
+    last_write = {}
+    n = 0
+    for t in ins:
+        if t[0] in ("label", "loop", "s_branch", "s_branch_if_ne0", "chunk_loop"):
+            last_write.clear()       # nothing is assumed across control flow: every target starts with instructions that
+            #                          read no VALU-written SGPR within two slots (checked by assert_targets_safe)
+        if t[0] in VALU:
+            need = 0
+            for r in sgpr_reads(t):
+                if r in last_write:
+                    need = max(need, 2 - (n - last_write[r] - 1))
+            if need > 0:
+                out.append(("s_nop", need - 1))
+                n += need
+            w = sgpr_write(t)
+            if w is not None:
+                last_write[w] = n
+        out.append(t)
+        n += 1
+    return out
+
+
+def assert_targets_safe(ins):
+    """After a label the first two VALU instructions must not read a carry / mask SGPR (their writer may be the last
+    instruction before the branch)."""
+    for k, t in enumerate(ins):
+        if t[0] == "label":
+            seen = 0
+            for u in ins[k + 1:]:
+                if u[0] in VALU:
+                    assert not [r for r in sgpr_reads(u) if r < SB_CONST], (t, u)
+                    seen += 1
+                    if seen == 2:
+                        break
+
+
+# ---- one-lane interpreter -------------------------------------------------------------------------------------------------
+class Machine:
+    def __init__(self):
+        self.v = {}
+        self.s = {}
+
+    def rd(self, a):
+        if isinstance(a, int):
+            return a & M64 if a >= 0 else a & M32     # inline constants: -1 is 0xFFFFFFFF as a 32-bit source
+        k, i = a
+        if k == "v":
+            return self.v[i]
+        if k == "vp":
+            return self.v[i] | (self.v[i + 1] << 32)
+        if k == "sp":
+            return self.s[i] | (self.s[i + 1] << 32)
+        raise ValueError(a)
+
+    def wr(self, a, val):
+        k, i = a
+        if k == "v":
+            self.v[i] = val & M32
+        elif k == "vp":
+            self.v[i], self.v[i + 1] = val & M32, (val >> 32) & M32
+        elif k == "sp":
+            self.s[i], self.s[i + 1] = val & M32, (val >> 32) & M32
+
+
+def run(ins, mem, state, leaf=None):
+    """mem: {"tab": dwords, "rc": dwords}; state: 12 lanes copied in; leaf: the lane's elements (sponge statement)."""
+    m = Machine()
+    labels = {t[1]: k for k, t in enumerate(ins) if t[0] == "label"}
+    pc = steps = 0
+    ptr = ("tab", 0)
+    col = 0
+    while pc < len(ins):
+        t = ins[pc]
+        op = t[0]
+        pc += 1
+        steps += 1
+        if op == "copy_in":
+            for i, x in enumerate(state):
+                m.wr(vp(A[i][0]), x)
+            m.v[E0 + 1] = m.v[E0 + 3] = 0
+        elif op == "copy_out":
+            break
+        elif op == "zero_in":
+            for i in range(12):
+                m.wr(vp(A[i][0]), 0)
+            m.v[E0 + 1] = m.v[E0 + 3] = 0
+        elif op == "digest_out":
+            break
+        elif op == "sponge_init":
+            m.s[SB_LOOP + 4], m.s[SB_LOOP + 5] = 0, len(leaf)
+        elif op == "s_rem":
+            m.s[S_CNT] = m.s[SB_LOOP + 5] - m.s[SB_LOOP + 4]
+        elif op == "gload":
+            if m.s[S_CNT] > t[2] + t[3]:
+                m.wr(t[1], leaf[col])
+                col += 1
+        elif op == "take":
+            if m.s[S_CNT] > t[3]:
+                m.wr(t[1], m.rd(t[2]))
+        elif op == "chunk_loop":
+            m.s[SB_LOOP + 4] += 8
+            if m.s[SB_LOOP + 4] < m.s[SB_LOOP + 5]:
+                pc = labels[t[1]]
+        elif op == "mad":
+            _, d, c, x, y, z = t
+            a, b = m.rd(x), m.rd(y)
+            assert a <= M32 and b <= M32
+            r = a * b + (m.rd(z) if z != 0 else 0)
+            m.wr(d, r & M64)
+            assert (r >> 64) <= 1
+            if c != "vcc":
+                m.wr(c, r >> 64)      # the lane's bit of the carry mask
+            else:
+                assert r >> 64 == 0, "carry into the scratch destination would be lost"
+        elif op == "addco":
+            r = m.rd(t[3]) + m.rd(t[4])
+            m.wr(t[1], r & M32)
+            m.wr(t[2], r >> 32)
+        elif op == "subco":
+            a, b = m.rd(t[3]), m.rd(t[4])
+            m.wr(t[1], (a - b) & M32)
+            m.wr(t[2], 1 if a < b else 0)
+        elif op == "subbco":
+            a, b, c = m.rd(t[3]), m.rd(t[4]), m.rd(t[5]) & 1
+            m.wr(t[1], (a - b - c) & M32)
+            m.wr(t[2], 1 if a < b + c else 0)
+        elif op == "s_xor":
+            m.wr(t[1], m.rd(t[2]) ^ m.rd(t[3]))
+        elif op == "s_and":
+            m.wr(t[1], m.rd(t[2]) & m.rd(t[3]))
+        elif op == "cmplt64":
+            m.wr(t[1], 1 if m.rd(t[2]) < m.rd(t[3]) else 0)
+        elif op == "mov":
+            m.wr(t[1], m.rd(t[2]))
+        elif op == "cnd":
+            m.wr(t[1], m.rd(t[3]) if m.rd(t[4]) & 1 else m.rd(t[2]))
+        elif op == "sub":
+            m.wr(t[1], (m.rd(t[2]) - m.rd(t[3])) & M32)
+        elif op == "add64":
+            m.wr(t[1], (m.rd(t[2]) + m.rd(t[3])) & M64)
+        elif op == "s_mov":
+            m.s[t[1]] = t[2]
+        elif op == "s_ptr":
+            ptr = (t[1], 0)
+        elif op == "s_add_ptr":
+            ptr = (ptr[0], ptr[1] + t[1])
+        elif op in ("s_load16", "s_load8"):
+            n = 16 if op == "s_load16" else 8
+            base = (ptr[1] + t[2]) // 4
+            for k in range(n):
+                m.s[t[1] + k] = mem[ptr[0]][base + k]
+        elif op in ("s_waitcnt", "s_waitcnt_all", "label", "s_nop"):
+            pass
+        elif op == "loop":
+            m.s[t[1]] -= 1
+            if m.s[t[1]] != 0:
+                pc = labels[t[2]]
+        elif op == "s_branch":
+            pc = labels[t[1]]
+        elif op == "s_branch_if_ne0":
+            if m.s[t[1]] != 0:
+                pc = labels[t[2]]
+        else:
+            raise ValueError(op)
+    out = [m.rd(vp(A[i][0])) for i in range(12)]
+    return out, False, steps
+
+
+# ---- printing ---------------------------------------------------------------------------------------------------------------
+def fmt(a):
+    if isinstance(a, int):
+        return str(a)
+    if a == "vcc":
+        return "vcc"
+    k, i = a
+    return {"v": "v%d" % i, "vp": "v[%d:%d]" % (i, i + 1), "sp": "s[%d:%d]" % (i, i + 1)}[k]
+
+
+def text(ins):
+    L = []
+    for t in ins:
+        op = t[0]
+        if op == "copy_in":
+            for i in range(12):
+                L.append("v_mov_b64 v[%d:%d], %%[x%d]" % (A[i][0], A[i][1], i))
+            L.append("v_mov_b32 v%d, 0" % (E0 + 1))
+            L.append("v_mov_b32 v%d, 0" % (E0 + 3))
+        elif op == "copy_out":
+            for i in range(12):
+                L.append("v_mov_b64 %%[x%d], v[%d:%d]" % (i, A[i][0], A[i][1]))
+        elif op == "sponge_init":
+            L.append("s_mov_b64 s[%d:%d], %%[col]" % (SB_LOOP, SB_LOOP + 1))
+            L.append("s_mov_b64 s[%d:%d], %%[stride]" % (SB_LOOP + 2, SB_LOOP + 3))
+            L.append("s_mov_b32 s%d, 0" % (SB_LOOP + 4))
+            L.append("s_mov_b32 s%d, %%[len]" % (SB_LOOP + 5))
+        elif op == "zero_in":
+            for i in range(12):
+                L.append("v_mov_b64 v[%d:%d], 0" % (A[i][0], A[i][1]))
+            L.append("v_mov_b32 v%d, 0" % (E0 + 1))
+            L.append("v_mov_b32 v%d, 0" % (E0 + 3))
+        elif op == "digest_out":
+            for i in range(4):
+                L.append("v_mov_b64 %%[o%d], v[%d:%d]" % (i, A[i][0], A[i][1]))
+        elif op == "s_rem":       # remaining = len - idx; element idx + k exists iff remaining > k
+            L.append("s_sub_u32 s%d, s%d, s%d" % (S_CNT, SB_LOOP + 5, SB_LOOP + 4))
+        elif op == "gload":
+            k = t[2] + t[3]
+            skip = "Lpos_skip%d_%d_%d_%%=" % (len(L), t[2], t[3])
+            L.append("s_cmp_gt_u32 s%d, %d" % (S_CNT, k))
+            L.append("s_cbranch_scc0 " + skip)
+            L.append("global_load_dwordx2 %s, %%[off], s[%d:%d]" % (fmt(t[1]), SB_LOOP, SB_LOOP + 1))
+            L.append("s_add_u32 s%d, s%d, s%d" % (SB_LOOP, SB_LOOP, SB_LOOP + 2))
+            L.append("s_addc_u32 s%d, s%d, s%d" % (SB_LOOP + 1, SB_LOOP + 1, SB_LOOP + 3))
+            L.append(skip + ":")
+        elif op == "take":
+            skip = "Lpos_keep%d_%d_%%=" % (len(L), t[3])
+            L.append("s_cmp_gt_u32 s%d, %d" % (S_CNT, t[3]))
+            L.append("s_cbranch_scc0 " + skip)
+            L.append("v_mov_b64 %s, %s" % (fmt(t[1]), fmt(t[2])))
+            L.append(skip + ":")
+        elif op == "chunk_loop":
+            L.append("s_add_u32 s%d, s%d, 8" % (SB_LOOP + 4, SB_LOOP + 4))
+            L.append("s_cmp_lt_u32 s%d, s%d" % (SB_LOOP + 4, SB_LOOP + 5))
+            L.append("s_cbranch_scc1 Lpos_%s_%%=" % t[1])
+        elif op == "mad":
+            L.append("v_mad_u64_u32 %s, %s, %s, %s, %s" % tuple(fmt(a) for a in t[1:]))
+        elif op == "addco":
+            L.append("v_add_co_u32 %s, %s, %s, %s" % tuple(fmt(a) for a in t[1:]))
+        elif op == "cmplt64":
+            L.append("v_cmp_lt_u64 %s, %s, %s" % tuple(fmt(a) for a in t[1:]))
+        elif op == "mov":
+            L.append("v_mov_b32 %s, %s" % (fmt(t[1]), fmt(t[2])))
+        elif op == "cnd":
+            L.append("v_cndmask_b32 %s, %s, %s, %s" % tuple(fmt(a) for a in t[1:]))
+        elif op == "sub":
+            L.append("v_sub_u32 %s, %s, %s" % tuple(fmt(a) for a in t[1:]))
+        elif op == "add64":
+            L.append("v_lshl_add_u64 %s, %s, 0, %s" % tuple(fmt(a) for a in t[1:]))
+        elif op == "subco":
+            L.append("v_sub_co_u32 %s, %s, %s, %s" % tuple(fmt(a) for a in t[1:]))
+        elif op == "subbco":
+            L.append("v_subb_co_u32 %s, %s, %s, %s, %s" % tuple(fmt(a) for a in t[1:]))
+        elif op == "s_xor":
+            L.append("s_xor_b64 %s, %s, %s" % tuple(fmt(a) for a in t[1:]))
+        elif op == "s_and":
+            L.append("s_and_b64 %s, %s, %s" % tuple(fmt(a) for a in t[1:]))
+        elif op == "s_mov":
+            L.append("s_mov_b32 s%d, %d" % (t[1], t[2]))
+        elif op == "s_ptr":
+            L.append("s_mov_b64 s[%d:%d], %%[%s]" % (S_PTR, S_PTR + 1, t[1]))
+        elif op == "s_add_ptr":
+            L.append("s_add_u32 s%d, s%d, %d" % (S_PTR, S_PTR, t[1]))
+            L.append("s_addc_u32 s%d, s%d, 0" % (S_PTR + 1, S_PTR + 1))
+        elif op == "s_load16":
+            L.append("s_load_dwordx16 s[%d:%d], s[%d:%d], 0x%x" % (t[1], t[1] + 15, S_PTR, S_PTR + 1, t[2]))
+        elif op == "s_load8":
+            L.append("s_load_dwordx8 s[%d:%d], s[%d:%d], 0x%x" % (t[1], t[1] + 7, S_PTR, S_PTR + 1, t[2]))
+        elif op == "s_waitcnt":
+            L.append("s_waitcnt lgkmcnt(0)")
+        elif op == "s_waitcnt_all":
+            L.append("s_waitcnt vmcnt(0) lgkmcnt(0)")
+        elif op == "s_nop":
+            L.append("s_nop %d" % t[1])
+        elif op == "label":
+            L.append("Lpos_%s_%%=:" % t[1])
+        elif op == "loop":
+            L.append("s_sub_u32 s%d, s%d, 1" % (t[1], t[1]))
+            L.append("s_cmp_lg_u32 s%d, 0" % t[1])
+            L.append("s_cbranch_scc1 Lpos_%s_%%=" % t[2])
+        elif op == "s_branch":
+            L.append("s_branch Lpos_%s_%%=" % t[1])
+        elif op == "s_branch_if_ne0":
+            L.append("s_cmp_lg_u32 s%d, 0" % t[1])
+            L.append("s_cbranch_scc1 Lpos_%s_%%=" % t[2])
+        else:
+            raise ValueError(op)
+    return L
+
+
+UNIT = {"mad": 1.7, "mov": 1.0, "cnd": 1.0, "sub": 1.0, "add64": 1.4, "addco": 2.6, "subco": 2.6, "subbco": 2.6,
+        "cmplt64": 1.4, "s_nop": 0.4}
+
+
+def dynamic_counts(ins):
+    labels = {t[1]: k for k, t in enumerate(ins) if t[0] == "label"}
+    loops = [k for k, t in enumerate(ins) if t[0] == "loop"]
+
+    def count(lo, hi):
+        c = {}
+        for t in ins[lo:hi]:
+            c[t[0]] = c.get(t[0], 0) + 1
+        return c
+    full_c = count(labels["full"], loops[0])
+    part_c = count(labels["part"], loops[1])
+    dyn = {k: 8 * full_c.get(k, 0) + 11 * part_c.get(k, 0) for k in set(full_c) | set(part_c)}
+    valu = sum(n for k, n in dyn.items() if k in UNIT and k != "s_nop")
+    units = sum(UNIT[k] * n for k, n in dyn.items() if k in UNIT)
+    return valu, dyn.get("s_nop", 0), units
+
+
+def write_macro(f, name, lines):
+    f.write("#define %s \\\n" % name)
+    for ln in lines:
+        f.write('  "%s\\n" \\\n' % ln)
+    f.write('  ""\n')
+
+
+def main():
+    out_dir = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.abspath(__file__)), "..",
+                                                                 "plonky2_bn254_amd", "csrc")
+    rc = round_constants()
+    tab = init_table(rc)
+    mem = {"tab": table_dwords(tab), "rc": [w for c in rc[:12] for w in (c & M32, c >> 32)]}
+    if EXPERIMENT:
+        ins = pad_hazards(build_permute().ins)
+        with open(os.path.join(out_dir, "poseidon_asm_%s.inc" % EXPERIMENT.replace(",", "_")), "w") as f:
+            write_macro(f, "POSEIDON_ASM_EXP_" + EXPERIMENT.replace(",", "_").upper(), text(ins))
+        print("experiment", EXPERIMENT, dynamic_counts(ins))
+        return
+    perm = pad_hazards(build_permute().ins)
+    sponge = pad_hazards(build_sponge().ins)
+    assert_targets_safe(perm)
+    assert_targets_safe(sponge)
+
+    # ---- check: interpreter vs the textbook permutation ----
+    def check(state):
+        pre = [(x + rc[i]) % P for i, x in enumerate(state)]     # the caller adds round 0's constants
+        got, bad, steps = run(perm, mem, pre)
+        assert [g % P for g in got] == permute(state, rc), state
+        return bad, steps
+    rnd = random.Random(1)
+    n_bad = steps = 0
+    for inp, _ in KATS:
+        assert not check(inp)[0]
+    for _ in range(int(os.environ.get("POSEIDON_GEN_TESTS", "60"))):
+        st = [rnd.randrange(P) for _ in range(12)]
+        if rnd.random() < 0.3:
+            st = [rnd.choice([0, 1, P - 1, (1 << 32) - 1, 1 << 32, rnd.randrange(1 << 16)]) for _ in range(12)]
+        b, steps = check(st)
+        n_bad += b
+    # sponge: hash_no_pad of ragged leaves from non-canonical-looking state words
+    for n in (1, 5, 8, 9, 16, 21):
+        leaf = [rnd.randrange(P) if rnd.random() < 0.7 else rnd.choice([0, P - 1, 1]) for _ in range(n)]
+        got, bad, _ = run(sponge, mem, None, leaf)
+        st = [0] * 12
+        for c in range(0, n, 8):
+            st[:len(leaf[c:c + 8])] = leaf[c:c + 8]
+            st = permute(st, rc)
+        assert [g % P for g in got[:4]] == st[:4], n
+    valu, nops, units = dynamic_counts(perm)
+    print("interpreter ok (%d instructions executed per permutation)" % steps)
+    print("VALU instructions per permutation: %d (+%d s_nop), %.0f simple-op slots; VGPRs v%d..v%d" %
+          (valu, nops, units, VB, V_END - 1))
+
+    with open(os.path.join(out_dir, "poseidon_asm.inc"), "w") as f:
+        f.write("// Generated by tools/gen_poseidon_asm.py - do not edit.  Hand-scheduled Poseidon-Goldilocks for gfx950; see the\n"
+                "// generator for the algorithm.  %d VALU instructions per permutation.\n"
+                "// POSEIDON_ASM_PERMUTE: x0..x11 = the twelve lanes (64-bit, in/out, round 0's constants already added, any\n"
+                "//   representative below 2^64 comes back), tab = POSEIDON_INIT_DEV.\n"
+                "// POSEIDON_ASM_SPONGE: hash_no_pad of one leaf per lane from the zero state: o0..o3 = digest (out, any\n"
+                "//   representative), col = address of element 0 of lane offset 0, off = the lane's byte offset (32 bits), stride =\n"
+                "//   bytes between consecutive elements, len = leaf length (> 0), rc = POSEIDON_RC_DEV, tab as above; also\n"
+                "//   clobbers POSEIDON_ASM_SPONGE_CLOBBERS (the staging registers of the next chunk's loads).\n" % valu)
+        f.write("#define POSEIDON_ASM_VGPR_FIRST %d\n#define POSEIDON_ASM_VGPR_LAST %d\n" % (VB, V_END - 1))
+        write_macro(f, "POSEIDON_ASM_PERMUTE", text(perm))
+        write_macro(f, "POSEIDON_ASM_SPONGE", text(sponge))
+        f.write("#define POSEIDON_ASM_SPONGE_CLOBBERS " + ", ".join('"v%d"' % i for i in range(LD0, LD0 + 16)) + "\n")
+        clob = ['"v%d"' % i for i in range(VB, V_END)] + ['"s%d"' % i for i in list(range(SB_LOOP, SB_LOOP + 6)) + list(range(SB_CARRY, S_HALF + 1)) + [30, 31, 34, 35, 22, 23]] + ['"vcc"', '"scc"']
+        f.write("#define POSEIDON_ASM_CLOBBERS " + ", ".join(clob) + "\n")
+    with open(os.path.join(out_dir, "poseidon_init.inc"), "w") as f:
+        f.write("/* Initial digit sums of the MDS layer of every round (tools/gen_poseidon_asm.py: init_table): per round and output\n"
+                "   lane four dwords (low 32 bits, 0, high 32 bits, 0) of the constant the layer adds; 31 rounds (the last is padding). */\n")
+        d = mem["tab"]
+        for i in range(0, len(d), 8):
+            f.write("  " + ", ".join("0x%08xu" % x for x in d[i:i + 8]) + ",\n")
+    print("wrote poseidon_asm.inc (%d + %d lines), poseidon_init.inc (%d dwords)" % (len(text(perm)), len(text(sponge)), len(mem["tab"])))
+
+
+if __name__ == "__main__":
+    main()
