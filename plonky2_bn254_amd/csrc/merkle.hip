@@ -36,12 +36,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
 #pragma unroll
     for (int i = 0; i < 4; i++) s[i] = t[i];
 #else
+    // the input of every permutation is parked here for the (rare) exact repeat: [lane of the state][thread], 96 B per thread
+    __shared__ u64 parked[12][256];
+    const u32 lds_addr = (u32)(uintptr_t)(__attribute__((address_space(3))) u64*)&parked[0][threadIdx.x];
     const u32 byte_off = lane_off * 8u;
     const u64 stride_bytes = (u64)elem_stride * 8u;
     asm volatile(POSEIDON_ASM_SPONGE
                  : [o0] "=&v"(s[0]), [o1] "=&v"(s[1]), [o2] "=&v"(s[2]), [o3] "=&v"(s[3])
                  : [col] "s"(data), [off] "v"(byte_off), [stride] "s"(stride_bytes), [len] "s"(leaf_len),
-                   [rc] "s"(POSEIDON_RC_DEV), [tab] "s"(POSEIDON_INIT_DEV)
+                   [rc] "s"(POSEIDON_RC_DEV), [tab] "s"(POSEIDON_INIT_DEV), [lds] "v"(lds_addr)
                  : POSEIDON_ASM_CLOBBERS, POSEIDON_ASM_SPONGE_CLOBBERS, "memory");
 #pragma unroll
     for (int i = 0; i < 4; i++) s[i] = s[i] >= GL_P ? s[i] - GL_P : s[i];

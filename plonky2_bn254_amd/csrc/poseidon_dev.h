@@ -159,9 +159,12 @@ __device__ __forceinline__ void poseidon_permute_plain(u64 s[12]) {
   for (int i = 0; i < 12; i++) s[i] = s[i] >= GL_P ? s[i] - GL_P : s[i];
 }
 
-// Hand-scheduled permutation (tools/gen_poseidon_asm.py -> poseidon_asm.inc): 17.2 k vector instructions instead of the
-// compiler's 24.4 k, exact for every input (every intermediate is "some representative below 2^64").  The statement owns
-// v26..v125 and the scalar registers listed in POSEIDON_ASM_CLOBBERS; callers should keep little else alive across it.
+// Hand-scheduled permutation (tools/gen_poseidon_asm.py -> poseidon_asm.inc): 12.5 k half-rate + 6 k full-rate vector
+// instructions instead of the compiler's 24.4 k (of which 18 k half-rate); every intermediate is "some representative below
+// 2^64".  The fast code's short forms do not cover a few digit patterns; running min / max registers detect them and the
+// statement then repeats the permutation with its exact code (about one wave-permutation in 100), so the result is exact for
+// every input.  The statement owns v26..v126 and the scalar registers listed in POSEIDON_ASM_CLOBBERS; callers should keep
+// little else alive across it.
 // BN254S_POSEIDON_PLAIN (compile time) selects the compiler's code everywhere (A/B measurements, tools/ubench).
 #include "poseidon_asm.inc"
 #endif
