@@ -75,7 +75,12 @@ typedef struct bn254s_params {
 void bn254s_params_default(bn254s_params* p);
 int bn254s_abi_version(void);
 
-/* One context per GPU: owns the HIP stream(s), twiddle tables and the pooled device workspace. */
+/* One context per GPU: owns the HIP stream(s), twiddle tables and the pooled device workspace.
+ * SURVEY.md section 8(b) sketched `bn254s_ctx_create(device_ids, n)` and `device_mask` / `batch_mode` fields in
+ * bn254s_params; this ABI keeps the parameters a pure restatement of StarkConfig and expresses both ideas as calls instead:
+ * one context per device (this function, any number of times) + bn254s_prove_batch_multi(ctxs, n_ctx, ...) for "these
+ * devices", and bn254s_prove_g1 (one proof for all jobs, what Bn254Hook::constrain needs) vs bn254s_prove_batch (independent
+ * per_proof-sized proofs) for the batch mode. */
 int bn254s_ctx_create(int device_id, bn254s_ctx** out);
 void bn254s_ctx_destroy(bn254s_ctx* ctx);
 const char* bn254s_last_error(const bn254s_ctx* ctx);
@@ -112,6 +117,28 @@ int bn254s_prove_fq_exp(bn254s_ctx* ctx, const bn254s_params* params, const uint
 
 /* Proof accessors.  Pointers stay valid until bn254s_proof_free. */
 int bn254s_proof_words(const bn254s_proof* p, const uint64_t** data, size_t* len);
+/* Per-field accessor: the words of one field of StarkProofWithMetadata (reference common/prover.rs:66-71), i.e. what
+ * set_stark_proof_target (generators/g1/stark_proof.rs:173) walks field by field.  Extension elements are two words
+ * (c0, c1), digests four, a cap 16 digests; BN254S_SEC_QUERY_ROUNDS is the 84 query rounds back to back in the layout
+ * documented at the top of this file (per round: three initial-tree openings, then one opening per FRI layer). */
+enum {
+  BN254S_SEC_TRACE_CAP = 0,
+  BN254S_SEC_AUX_CAP = 1,
+  BN254S_SEC_QUOTIENT_CAP = 2,
+  BN254S_SEC_LOCAL_VALUES = 3,
+  BN254S_SEC_NEXT_VALUES = 4,
+  BN254S_SEC_AUX_POLYS = 5,
+  BN254S_SEC_AUX_POLYS_NEXT = 6,
+  BN254S_SEC_CTL_ZS_FIRST = 7,
+  BN254S_SEC_QUOTIENT_POLYS = 8,
+  BN254S_SEC_FRI_CAPS = 9,
+  BN254S_SEC_QUERY_ROUNDS = 10,
+  BN254S_SEC_FINAL_POLY = 11,
+  BN254S_SEC_POW_WITNESS = 12,
+  BN254S_SEC_INIT_CHALLENGER_STATE = 13,
+  BN254S_SEC_COUNT = 14
+};
+int bn254s_proof_section(const bn254s_proof* p, int id, const uint64_t** data, size_t* len);
 int bn254s_proof_degree_bits(const bn254s_proof* p);
 /* n x (8 | 16 | 4) words: the outputs s*x+offset (what run_once writes with set_witness at :147-149). */
 int bn254s_proof_outputs(const bn254s_proof* p, const uint64_t** data, size_t* len);

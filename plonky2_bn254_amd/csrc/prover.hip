@@ -60,6 +60,7 @@ static const char* STAGE_NAMES[ST_COUNT] = {"trace_gen", "trace_ntt", "trace_mer
 
 struct bn254s_proof {
   std::vector<u64> words, outputs;
+  size_t sec_off[BN254S_SEC_COUNT + 1] = {0};  // bn254s_proof_section: start of every field of the word layout
   int degree_bits = 0;
   float stage_ms[ST_COUNT] = {0};
 };
@@ -617,18 +618,31 @@ static int prove_on_slot(bn254s_ctx* c, Slot& sl, int kind, const bn254s_params&
   std::vector<u64>& o = pr->words;
   o.clear();
   o.reserve(3 * CAPW + 4 * (W + A) + n_ctlz + 2 * NQ + L * CAPW + n_q + 2 * final_poly.size() + 13);
-  for (int t = 0; t < 3; t++) o.insert(o.end(), caps[t], caps[t] + CAPW);
+  auto mark = [&](int id) { pr->sec_off[id] = o.size(); };
+  for (int t = 0; t < 3; t++) { mark(BN254S_SEC_TRACE_CAP + t); o.insert(o.end(), caps[t], caps[t] + CAPW); }
+  mark(BN254S_SEC_LOCAL_VALUES);
   for (int p = 0; p < W; p++) { o.push_back(op(p, 0)); o.push_back(op(p, 1)); }
+  mark(BN254S_SEC_NEXT_VALUES);
   for (int p = 0; p < W; p++) { o.push_back(op(p, 2)); o.push_back(op(p, 3)); }
+  mark(BN254S_SEC_AUX_POLYS);
   for (int p = W; p < W + A; p++) { o.push_back(op(p, 0)); o.push_back(op(p, 1)); }
+  mark(BN254S_SEC_AUX_POLYS_NEXT);
   for (int p = W; p < W + A; p++) { o.push_back(op(p, 2)); o.push_back(op(p, 3)); }
+  mark(BN254S_SEC_CTL_ZS_FIRST);
   for (int i = 0; i < n_ctlz; i++) o.push_back(op(W + num_lookup + i, 4));
+  mark(BN254S_SEC_QUOTIENT_POLYS);
   for (int p = W + A; p < W + A + NQ; p++) { o.push_back(op(p, 0)); o.push_back(op(p, 1)); }
+  mark(BN254S_SEC_FRI_CAPS);
   for (int l = 0; l < L; l++) o.insert(o.end(), layer_caps[l].begin(), layer_caps[l].end());
+  mark(BN254S_SEC_QUERY_ROUNDS);
   o.insert(o.end(), h_q, h_q + n_q);
+  mark(BN254S_SEC_FINAL_POLY);
   for (auto& cf : final_poly) { o.push_back(cf.c0); o.push_back(cf.c1); }
+  mark(BN254S_SEC_POW_WITNESS);
   o.push_back(pow_witness);
+  mark(BN254S_SEC_INIT_CHALLENGER_STATE);
   o.insert(o.end(), init_state, init_state + 12);
+  mark(BN254S_SEC_COUNT);
   pr->degree_bits = log_n;
   for (int i = 0; i < ST_COUNT; i++) hipEventElapsedTime(&pr->stage_ms[i], ev[2 * i], ev[2 * i + 1]);
   cleanup_events();
@@ -791,6 +805,12 @@ int bn254s_proof_words(const bn254s_proof* p, const uint64_t** data, size_t* len
   if (!p || !data || !len) return BN254S_E_INVALID_ARG;
   *data = p->words.data();
   *len = p->words.size();
+  return BN254S_OK;
+}
+int bn254s_proof_section(const bn254s_proof* p, int id, const uint64_t** data, size_t* len) {
+  if (!p || !data || !len || id < 0 || id >= BN254S_SEC_COUNT) return BN254S_E_INVALID_ARG;
+  *data = p->words.data() + p->sec_off[id];
+  *len = p->sec_off[id + 1] - p->sec_off[id];
   return BN254S_OK;
 }
 int bn254s_proof_degree_bits(const bn254s_proof* p) { return p ? p->degree_bits : 0; }

@@ -58,6 +58,7 @@ def load_library():
     lib.bn254s_proof_words.argtypes = [vp, C.POINTER(U64P), C.POINTER(C.c_size_t)]
     lib.bn254s_proof_outputs.argtypes = [vp, C.POINTER(U64P), C.POINTER(C.c_size_t)]
     lib.bn254s_proof_degree_bits.argtypes = [vp]
+    lib.bn254s_proof_section.argtypes = [vp, C.c_int, C.POINTER(U64P), C.POINTER(C.c_size_t)]
     lib.bn254s_proof_stage_ms.argtypes = [vp, C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.c_size_t)]
     lib.bn254s_stage_name.argtypes = [C.c_size_t]
     lib.bn254s_stage_name.restype = C.c_char_p
@@ -105,6 +106,18 @@ class Proof:
         ms, k = C.POINTER(C.c_float)(), C.c_size_t()
         lib.bn254s_proof_stage_ms(handle, C.byref(ms), C.byref(k))
         self.stage_ms = {lib.bn254s_stage_name(i).decode(): float(ms[i]) for i in range(k.value)}
+
+    SECTIONS = ("trace_cap", "auxiliary_polys_cap", "quotient_polys_cap", "local_values", "next_values", "auxiliary_polys",
+                "auxiliary_polys_next", "ctl_zs_first", "quotient_polys", "commit_phase_merkle_caps", "query_round_proofs",
+                "final_poly", "pow_witness", "init_challenger_state")
+
+    def section(self, name: str) -> np.ndarray:
+        """One field of StarkProofWithMetadata (bn254s_proof_section): a copy of its words."""
+        data, n = U64P(), C.c_size_t()
+        rc = self._lib.bn254s_proof_section(self._h, self.SECTIONS.index(name), C.byref(data), C.byref(n))
+        if rc != 0:
+            raise RuntimeError(f"bn254s_proof_section({name}) failed with {rc}")
+        return np.ctypeslib.as_array(data, shape=(n.value,)).copy() if n.value else np.zeros(0, np.uint64)
 
     def serialize(self) -> bytes:
         """Little-endian bytes of the word layout (bn254s_proof_serialize)."""

@@ -107,3 +107,27 @@ def test_ctl_values_rows_without_gpu():
     assert lib.bn254s_ctl_values(2, L._ptr(fs), L._ptr(fx), None, L._ptr(fo), 2, L._ptr(ri), L._ptr(ro)) == 0
     assert ri[1].tolist() == limbs(fx[1]) + limbs(fs[1]) + [1] and ro[1].tolist() == [1] + [0] * 15 + [1]
     assert lib.bn254s_ctl_values(0, L._ptr(s), L._ptr(x), None, L._ptr(outs), 3, L._ptr(ri), L._ptr(ro)) == -1
+
+
+def test_fixture_tools_column_digest_and_io_round_trip(tmp_path):
+    """tools/compare_fixture.py: the numpy column digest equals the fold rust/shim/dump_fixture.rs computes, and the dump /
+    input text formats survive a round trip (the GPU part of the comparison is rehearsed in tests/test_gpu_fixture.py)."""
+    from tools import compare_fixture as cf
+    from tools import export_fixture_inputs as ex
+    t = np.array([[1, 2, 3], [5, 0, 0xFFFFFFFFFFFFFFFF]], dtype=np.uint64)
+    want = []
+    for col in t:
+        d = 0
+        for v in col:
+            d = (d * cf.DIGEST_K + int(v)) & 0xFFFFFFFFFFFFFFFF
+        want.append(d)
+    assert [int(v) for v in cf.column_digests(t)] == want
+    words = np.arange(40, dtype=np.uint64) * np.uint64(0x0123456789ABCDEF)
+    cf.write_dump(str(tmp_path / "d.txt"), t, words)
+    nrows, dig, w = cf.parse_dump(str(tmp_path / "d.txt"))
+    assert nrows == 3 and [int(v) for v in dig] == want and np.array_equal(w, words)
+    for kind in ("g1", "fq"):
+        s, x, o = ex.inputs(kind, 2, 0xF1C5)
+        ex.write(str(tmp_path / "in.txt"), s, x, o)
+        s2, x2, o2 = ex.read(str(tmp_path / "in.txt"), kind)
+        assert np.array_equal(s, s2) and np.array_equal(x, x2) and (o is None) == (o2 is None)

@@ -1,14 +1,11 @@
-# Sweep of the scheduling knobs (tuning only): big-kernel semaphore, slots, hardware queues.
-set -e
+# Scheduler knob sweep (tuning only): proofs/s of batches of 8 under different semaphore costs / slot counts.
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/sweep
-L=gpurun_out/sweep/run.log
+mkdir -p gpurun_out/locksweep
+L=gpurun_out/locksweep/run.log
 : > $L
-run() { echo "== $*" | tee -a $L; env "$@" python tools/run_proofs.py 10 batch 2>&1 | tail -1 | tee -a $L; }
-run BN254S_SLOTS=6
-run BN254S_SLOTS=6 BN254S_BIG_COST_NTT=2
-run BN254S_SLOTS=6
-run BN254S_SLOTS=6 BN254S_BIG_COST_NTT=2
-run BN254S_SLOTS=8 BN254S_BIG_COST_NTT=2
-run BN254S_SLOTS=6 BN254S_BIG_CAP=4 BN254S_BIG_COST_NTT=3 BN254S_BIG_COST_EXCL=2
-run BN254S_SLOTS=8 BN254S_BIG_CAP=4 BN254S_BIG_COST_NTT=3 BN254S_BIG_COST_EXCL=2
+python tools/run_proofs.py 6 batch 2>&1 | tail -1 | tee -a $L
+for cfg in "3 3 2 1 6" "4 4 2 1 6" "4 4 3 1 6" "4 4 2 2 6" "2 2 2 1 6" "3 3 3 1 6" "3 3 2 1 8" "4 3 2 1 8" "6 6 3 2 8" "6 4 3 2 8" "3 2 2 1 6" "4 4 2 1 4"; do
+  set -- $cfg
+  echo "== cap $1 ntt $2 excl $3 hash $4 slots $5" | tee -a $L
+  BN254S_BIG_CAP=$1 BN254S_BIG_COST_NTT=$2 BN254S_BIG_COST_EXCL=$3 BN254S_BIG_COST_HASH=$4 BN254S_SLOTS=$5 python tools/run_proofs.py 6 batch 2>&1 | tail -1 | tee -a $L
+done
