@@ -2,7 +2,9 @@
 (SURVEY.md section 8(c) strategy (ii)).  The reference holds no fixture of its own (no seeded test), so these pin the oracle's
 output: `tests/test_gpu_golden.py` compares the GPU proofs against them without running the oracle.
 
-usage: python tools/gen_proof_golden.py > tests/golden/proof_digests.json   (about ten minutes on 8 cores)"""
+usage: python tools/gen_proof_golden.py > tests/golden/proof_digests.json   (about ten minutes on 8 cores)
+       python tools/gen_proof_golden.py --only g1_tall19 > one_case.json     (a single case; g1_tall19 = BASELINE configs[1] as
+       ONE proof of 2^19 rows, the shape Bn254Hook::constrain produces for 1024 calls: minutes on a many-core host, ~25 GB)"""
 import hashlib
 import json
 import sys
@@ -21,7 +23,11 @@ def digest(a):
 def main():
     lib = oracle_lib.load()
     cases = [("g1", 0, synth.g1_inputs, 2, 0xA1), ("g1_full", 0, synth.g1_inputs, 128, 0xA2), ("g2", 1, synth.g2_inputs, 2, 0xA3),
-             ("fq_exp", 2, synth.fq_inputs, 3, 0xA4)]
+             ("fq_exp", 2, synth.fq_inputs, 3, 0xA4), ("g1_tall19", 0, synth.g1_inputs, 1024, 0xA5)]
+    if len(sys.argv) > 2 and sys.argv[1] == "--only":
+        cases = [c for c in cases if c[0] == sys.argv[2]]
+    else:
+        cases = [c for c in cases if c[0] != "g1_tall19"]      # the tall case is generated on its own
     out = {}
     for name, kind, gen, n, seed in cases:
         ins = gen(n, seed=seed)
