@@ -153,10 +153,19 @@ void bn254s_proof_free(bn254s_proof* p);
  * against the claimed inputs and outputs (common/ctl_values.rs:28-47 with the rows of scalar_mul_ctl.rs:57-80 /
  * g2 twin / exp_ctl.rs:54-75; timestamps are 0..n-1).  kind 0 = G1, 1 = G2, 2 = Fq exp (offset NULL); outputs = the
  * n x (8 | 16 | 4) words of bn254s_proof_outputs.  Returns BN254S_OK, or BN254S_E_VERIFY with the reason in
- * bn254s_last_error.  The constraint sum at zeta is evaluated by the quotient kernels (csrc/verify.hip), so a GPU is needed. */
+ * bn254s_last_error.  With a context the constraint sum at zeta is evaluated by the quotient kernels (csrc/verify.hip); see
+ * bn254s_verify_host for the GPU-free form. */
 int bn254s_verify(bn254s_ctx* ctx, int kind, const bn254s_params* params, uint32_t degree_bits, const uint64_t* words,
                   size_t n_words, const uint64_t* scalars, const uint64_t* x, const uint64_t* offset, const uint64_t* outputs,
                   size_t n);
+/* The same verifier without a context and without a GPU: the constraint sum at zeta comes from an independent host statement
+ * of the three AIRs over the quadratic extension (csrc/verify_air_host.h, written from the reference's eval_packed_generic
+ * functions, not from the quotient kernels), everything else (transcript, FRI, Merkle paths, CTL sums) is host code in both.
+ * A few milliseconds per proof on one core.  On rejection the reference verifier's error text is copied to err_buf
+ * (may be NULL). */
+int bn254s_verify_host(int kind, const bn254s_params* params, uint32_t degree_bits, const uint64_t* words, size_t n_words,
+                       const uint64_t* scalars, const uint64_t* x, const uint64_t* offset, const uint64_t* outputs, size_t n,
+                       char* err_buf, size_t err_cap);
 
 /* The extra looking values of the two cross-table lookups (reference g1_generate_ctl_values, scalar_mul_ctl.rs:57-80; G2 twin;
  * fq_generate_ctl_values, exp_ctl.rs:54-75), i.e. what run_once hands to set_ctl_values_target (stark_proof.rs:174-178):

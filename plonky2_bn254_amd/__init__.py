@@ -10,4 +10,4 @@ import os as _os
 # one hardware queue per proof in flight (see csrc/capi.hip); must be in the environment before the HIP runtime starts
 _os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
-from .lib import Context, Proof, load_library, LibraryMissing, VerifyError, default_params, prove_batch_multi  # noqa: F401
+from .lib import Context, Proof, load_library, LibraryMissing, VerifyError, default_params, prove_batch_multi, verify_host  # noqa: F401

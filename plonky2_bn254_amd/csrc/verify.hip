@@ -20,6 +20,7 @@
 #include "prover.h"
 #include "quotient.h"
 #include "transcript.h"
+#include "verify_air_host.h"
 
 namespace {
 
@@ -307,8 +308,14 @@ int verify_impl(bn254s_ctx* c, int kind, const bn254s_params& P, int degree_bits
   gl2 l_last = gl2_mul(z_h, gl2_inv(gl2_mul_base(gl2_sub(gl2_mul_base(zeta, g), one), nF)));
   gl2 z_last = gl2_sub(zeta, base(gl_inv(g)));
   gl2 van[2];
-  int rc = vanishing_on_gpu(c, kind, sh, w, v, alphas, betas, gammas, z_last, l_first, l_last, van, err);
-  if (rc != BN254S_OK) return rc;
+  if (c) {  // batched hosts with a context: the constraint sum through the quotient kernels
+    int rc = vanishing_on_gpu(c, kind, sh, w, v, alphas, betas, gammas, z_last, l_first, l_last, van, err);
+    if (rc != BN254S_OK) return rc;
+  } else {  // no context: the independent host statement of the AIR (verify_air_host.h), no GPU involved
+    if (!host_air::vanishing_on_host(kind, sh, w + v.local, w + v.next, w + v.aux, w + v.aux_next, alphas, betas, gammas, z_last,
+                                     l_first, l_last, van, err))
+      return BN254S_E_INTERNAL;
+  }
   for (int j = 0; j < 2; j++) {
     gl2 t = gl2_add(ext(w + v.quot + 4 * j), gl2_mul(ext(w + v.quot + 4 * j + 2), zeta_pow));
     if (!gl2_eq(van[j], gl2_mul(z_h, t))) {
@@ -456,6 +463,28 @@ extern "C" int bn254s_ctl_values(int kind, const uint64_t* scalars, const uint64
     memcpy(out_rows + k * out.size(), out.data(), out.size() * 8);
   }
   return BN254S_OK;
+}
+
+extern "C" int bn254s_verify_host(int kind, const bn254s_params* params, uint32_t degree_bits, const uint64_t* words, size_t n_words,
+                                  const uint64_t* scalars, const uint64_t* x, const uint64_t* off, const uint64_t* outputs, size_t n,
+                                  char* err_buf, size_t err_cap) {
+  if (err_buf && err_cap) err_buf[0] = 0;
+  if (kind < 0 || kind > 2 || !params || params->struct_size != sizeof(bn254s_params) || !words || !scalars || !x ||
+      (kind != KIND_FQ && !off) || !outputs || n == 0 || degree_bits < 7 || degree_bits > 30)
+    return BN254S_E_INVALID_ARG;
+  std::string err;
+  int rc;
+  if (params->num_challenges != 2 || params->rate_bits != 1) {
+    err = "only num_challenges = 2, rate_bits = 1 are supported";
+    rc = BN254S_E_UNSUPPORTED;
+  } else {
+    rc = verify_impl(nullptr, kind, *params, (int)degree_bits, words, n_words, scalars, x, off, outputs, n, err);
+  }
+  if (rc != BN254S_OK && err_buf && err_cap) {
+    strncpy(err_buf, err.c_str(), err_cap - 1);
+    err_buf[err_cap - 1] = 0;
+  }
+  return rc;
 }
 
 extern "C" int bn254s_verify(bn254s_ctx* c, int kind, const bn254s_params* params, uint32_t degree_bits, const uint64_t* words,

@@ -66,6 +66,8 @@ def load_library():
     lib.bn254s_proof_serialize.argtypes = [vp, vp, C.c_size_t]
     lib.bn254s_proof_serialize.restype = C.c_size_t
     lib.bn254s_verify.argtypes = [vp, C.c_int, C.POINTER(Params), C.c_uint32, vp, C.c_size_t, vp, vp, vp, vp, C.c_size_t]
+    lib.bn254s_verify_host.argtypes = [C.c_int, C.POINTER(Params), C.c_uint32, vp, C.c_size_t, vp, vp, vp, vp, C.c_size_t, C.c_char_p,
+                                       C.c_size_t]
     lib.bn254s_map_to_g2.argtypes = [vp, C.POINTER(Params), vp, vp, C.c_size_t, vp, vp, vp, C.POINTER(vp), C.POINTER(vp)]
     lib.bn254s_hash_to_fq2.argtypes = [vp, C.c_size_t, vp]
     lib.bn254s_ctl_values.argtypes = [C.c_int, vp, vp, vp, vp, C.c_size_t, vp, vp]
@@ -292,6 +294,22 @@ class Context:
         self._check(self._lib.bn254s_g1_generate_trace(self._h, _ptr(scalars), _ptr(x), _ptr(offset), n, min_rows_log2,
                                                        _ptr(trace), _ptr(outs)), "bn254s_g1_generate_trace")
         return trace, outs
+
+
+def verify_host(kind, words, degree_bits, scalars, x, offset, outputs, params: Optional[Params] = None):
+    """bn254s_verify_host: the native verifier without a context or a GPU (the AIR is evaluated on the host over the quadratic
+    extension).  Returns None or raises VerifyError(reason)."""
+    lib = load_library()
+    params = params or default_params()
+    words = np.ascontiguousarray(words, dtype=np.uint64)
+    outputs = np.ascontiguousarray(outputs, dtype=np.uint64)
+    buf = C.create_string_buffer(256)
+    rc = lib.bn254s_verify_host(kind, C.byref(params), degree_bits, _ptr(words), words.size, _ptr(scalars), _ptr(x), _ptr(offset),
+                                _ptr(outputs), scalars.shape[0], buf, 256)
+    if rc == -8:
+        raise VerifyError(buf.value.decode())
+    if rc != 0:
+        raise RuntimeError(f"bn254s_verify_host failed with {rc}: {buf.value.decode()}")
 
 
 def prove_batch_multi(contexts, kind, scalars, x, offset=None, per_proof=128, params: Optional[Params] = None):

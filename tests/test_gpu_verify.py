@@ -53,6 +53,14 @@ def both_verify(gpu_ctx, oracle, p, words=None, s=None, x=None, o=None, outputs=
         mine = None
     except pk.VerifyError as e:
         mine = str(e)
+    # the GPU-free form (bn254s_verify_host: the AIR evaluated on the host over F2, an independent statement) must give the
+    # same verdict and the same text on every case of this file
+    try:
+        pk.verify_host(p["kind"], words, p["degree_bits"], s, x, o, outputs)
+        host = None
+    except pk.VerifyError as e:
+        host = str(e)
+    assert host == mine, (host, mine)
     rc, msg = oracle_lib.verify(oracle, p["kind"], words, p["degree_bits"], s, x, o)
     return mine, (None if rc == 0 else msg)
 

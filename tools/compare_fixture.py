@@ -52,7 +52,7 @@ def compare(ctx, kind: str, inputs_path: str, dump_path: str, out=print) -> bool
         out("trace: all %d column digests identical" % ref_digests.size)
     else:
         bad = np.flatnonzero(column_digests(trace) != ref_digests) if trace.shape == (ref_digests.size, nrows) else []
-        out("trace: DIFFERENT (shape %s vs %s, first columns %s)" % (trace.shape, (ref_digests.size, nrows), list(bad[:8])))
+        out("trace: DIFFERENT (shape %s vs %s, first columns %s)" % (trace.shape, (ref_digests.size, nrows), [int(c) for c in bad[:8]]))
     pr = {0: ctx.prove_g1, 1: ctx.prove_g2}[k](s, x, o) if k != 2 else ctx.prove_fq_exp(s, x)
     got = pr.words
     if got.size != ref.size:
