@@ -44,7 +44,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     asm volatile(POSEIDON_ASM_SPONGE
                  : [o0] "=&v"(s[0]), [o1] "=&v"(s[1]), [o2] "=&v"(s[2]), [o3] "=&v"(s[3])
                  : [col] "s"(data), [off] "v"(byte_off), [stride] "s"(stride_bytes), [len] "s"(leaf_len),
-                   [rc] "s"(POSEIDON_RC_DEV), [tab] "s"(POSEIDON_INIT_DEV), [lds] "v"(lds_addr)
+                   [rc] "s"(POSEIDON_RC_DEV), [tab] "s"(POSEIDON_INIT_DEV), [blk] "s"(POSEIDON_BLK_DEV),
+                   [lds] "v"(lds_addr)
                  : POSEIDON_ASM_CLOBBERS, POSEIDON_ASM_SPONGE_CLOBBERS, "memory");
 #pragma unroll
     for (int i = 0; i < 4; i++) s[i] = s[i] >= GL_P ? s[i] - GL_P : s[i];

@@ -159,9 +159,9 @@ __device__ __forceinline__ void poseidon_permute_plain(u64 s[12]) {
   for (int i = 0; i < 12; i++) s[i] = s[i] >= GL_P ? s[i] - GL_P : s[i];
 }
 
-// Hand-scheduled permutation (tools/gen_poseidon_asm.py -> poseidon_asm.inc): 12.5 k half-rate + 6 k full-rate vector
-// instructions instead of the compiler's 24.4 k (of which 18 k half-rate); every intermediate is "some representative below
-// 2^64".  The fast code's short forms do not cover a few digit patterns; running min / max registers detect them and the
+// Hand-scheduled permutation (tools/gen_poseidon_asm.py -> poseidon_asm.inc): 12.7 k vector instructions instead of the
+// compiler's 24.4 k (the 22 partial rounds run as seven blocks of three rounds with ONE linear layer each, plus one single
+// round); every intermediate is "some representative below 2^64".  The fast code's short forms do not cover a few digit patterns; running min / max registers detect them and the
 // statement then repeats the permutation with its exact code (about one wave-permutation in 100), so the result is exact for
 // every input.  The statement owns v26..v126 and the scalar registers listed in POSEIDON_ASM_CLOBBERS; callers should keep
 // little else alive across it.
@@ -170,6 +170,10 @@ __device__ __forceinline__ void poseidon_permute_plain(u64 s[12]) {
 #endif
 static __constant__ __attribute__((aligned(64))) u32 POSEIDON_INIT_DEV[31 * 48] = {
 #include "poseidon_init.inc"
+};
+// records of the merged partial-round blocks (three rounds per linear layer, tools/gen_poseidon_asm.py: block_tables)
+static __constant__ __attribute__((aligned(64))) u32 POSEIDON_BLK_DEV[7 * 15 * 16] = {
+#include "poseidon_blocks.inc"
 };
 
 // In place, canonical result.
@@ -184,7 +188,7 @@ GL_HD void poseidon_permute(u64 s[12]) {
   asm(POSEIDON_ASM_PERMUTE
       : [x0] "+v"(x[0]), [x1] "+v"(x[1]), [x2] "+v"(x[2]), [x3] "+v"(x[3]), [x4] "+v"(x[4]), [x5] "+v"(x[5]), [x6] "+v"(x[6]),
         [x7] "+v"(x[7]), [x8] "+v"(x[8]), [x9] "+v"(x[9]), [x10] "+v"(x[10]), [x11] "+v"(x[11])
-      : [tab] "s"(POSEIDON_INIT_DEV)
+      : [tab] "s"(POSEIDON_INIT_DEV), [blk] "s"(POSEIDON_BLK_DEV)
       : POSEIDON_ASM_CLOBBERS);
 #pragma unroll
   for (int i = 0; i < 12; i++) s[i] = x[i] >= GL_P ? x[i] - GL_P : x[i];

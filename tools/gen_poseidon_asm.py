@@ -42,15 +42,16 @@ TMP = VB + 48      # S-box stream temporaries / MDS digit sums
 N_STREAMS = 3
 STREAM_REGS = 16
 E0 = TMP + N_STREAMS * STREAM_REGS     # two pairs (e, 0): the "+ (2^32 - 1) if carry" addends of the exact code
-MN_A = E0                              # fast code: running min of the low digits al0 (fold needs al0 >= 2^10 > ah1) ...
-MX_A = E0 + 2                          # ... running max of ah0 (fold needs ah0 + al1 + ah1 < 2^32) - the low halves of the
-MN_R = E0 + 4                          # (e, 0) pairs, free while the fast code runs; running min of t.hi (reduction)
+MN_A = TMP + N_STREAMS * STREAM_REGS - 2    # fast code: running min of the low digits al0 (fold needs al0 >= 2^10 > ah1) ...
+MX_A = TMP + N_STREAMS * STREAM_REGS - 1    # ... running max of ah0 (fold needs ah0 + al1 + ah1 < 2^32): the two registers the last
+MN_R = E0 + 4                          # stream does not use (its X3 aliases X2); running min of t.hi (reduction)
 V_END = E0 + 5
 MODE = {"fast": True}
 A = [(A0 + 2 * i, A0 + 2 * i + 1) for i in range(12)]
 S = [(S0 + 2 * i, S0 + 2 * i + 1) for i in range(12)]
 LD0 = 10           # v10..v25: staging of the next chunk's eight loads (sponge statement only)
 SB_LOOP = 24       # s[24:29]: column pointer, column stride in bytes, element index, leaf length (sponge statement)
+S_BLK = 20         # s[20:21]: pointer to the records of the merged partial-round blocks
 SB_MASK = (30, 34, 22)    # s[30:31], s[34:35], s[22:23]: one scratch mask pair per stream (s32, s33 stay untouched)
 SB_CARRY = 36      # s[36:47]: two carry pairs per stream; the folds use the first four pairs
 SB_CONST = 48      # s[48:95]: the 48 dwords of one round of initial digit sums (or round 0's 12 constants)
@@ -112,6 +113,10 @@ def sp(i):
     return ("sp", i)
 
 
+def s1(i):
+    return ("s", i)
+
+
 def interleave(p, tasks):
     for t in round_robin(tasks):
         p.emit(*t)
@@ -171,7 +176,7 @@ def mul_task(a, b, dst, t, cA, cB, cT):
 def sbox_task(x, dst, stream):
     """x^7 of the lane held in the registers x = (lo, hi) -> the pair dst (dst may be x's own pair)."""
     t = TMP + stream * STREAM_REGS
-    X2, X3, X4 = t + 10, t + 12, t + 14
+    X2, X3, X4 = t + 10, t + 10, t + 12      # x^3 = x^2 * x is written (last instruction) where x^2 was read (first ones)
     cA, cB, cT = SB_CARRY + 4 * stream, SB_CARRY + 4 * stream + 2, SB_MASK[stream]
     yield from mul_task(x, x, X2, t, cA, cB, cT)
     yield from mul_task((X2, X2 + 1), (X2, X2 + 1), X4, t, cA, cB, cT)
@@ -309,6 +314,181 @@ def partial_round(p, src, dst, ratio=3):
     fold_group(p, dst, 2)
 
 
+# ---- three partial rounds per linear layer ------------------------------------------------------------------------------------
+# In a partial round only lane 0 is non-linear: with M' = M with column 0 removed, m0 = column 0 of M and t = S-box output,
+#   y = M' u + t m0 + k.  Three rounds composed:
+#   y0   = row0(M') u + t0 m0[0] + k0[0]                           -> t1 = sbox(y0)
+#   y'0  = row0(M'^2) u + t0 (M' m0)[0] + t1 m0[0] + (M' k0 + k1)[0]  -> t2 = sbox(y'0)
+#   y''  = M'^3 u + t0 M'^2 m0 + t1 M' m0 + t2 m0 + (M'^2 k0 + M' k1 + k2)
+# The integer matrices M'^2, M'^3 have entries below 2^15 / 2^24, so the 32-bit-digit sums still fit 64-bit accumulators:
+# 264 multiply-adds replace three layers of 290, the three S-boxes stay sequential but run beside the 308 multiply-adds that
+# do not depend on them.  Constants per block come from POSEIDON_BLK_DEV (15 records of 16 dwords, block_tables()).
+BLK_BYTES = 15 * 64
+
+
+def mat_M():
+    return [[MDS_CIRC[(i - j) % 12] + (8 if i == j == 0 else 0) for i in range(12)] for j in range(12)]
+
+
+def mat_mul(X, Y):
+    return [[sum(X[i][k] * Y[k][j] for k in range(12)) for j in range(12)] for i in range(12)]
+
+
+def mat_vec(X, v_, mod=None):
+    r = [sum(X[i][k] * v_[k] for k in range(12)) for i in range(12)]
+    return [x % mod for x in r] if mod else r
+
+
+def block_matrices():
+    M = mat_M()
+    Mp = [[0 if i == 0 else M[j][i] for i in range(12)] for j in range(12)]
+    m0 = [M[j][0] for j in range(12)]
+    Mp2 = mat_mul(Mp, Mp)
+    Mp3 = mat_mul(Mp2, Mp)
+    return M, Mp, Mp2, Mp3, m0, mat_vec(Mp, m0), mat_vec(Mp2, m0)
+
+
+def block_tables(tab):
+    """Records of the 7 blocks (rounds 4+3b .. 6+3b).  tab = init_table(rc): tab[r] is what round r's layer adds."""
+    M, Mp, Mp2, Mp3, m0, b, a = block_matrices()
+    assert max(sum(r) for r in Mp3) + max(a) + max(b) + 64 < 1 << 31        # every digit sum stays below 2^63
+    out = []
+    for blk in range(7):
+        r = 4 + 3 * blk
+        k0, k1, k2 = tab[r], tab[r + 1], tab[r + 2]
+        ky0 = k0[0]
+        ky1 = (mat_vec(Mp, k0, P)[0] + k1[0]) % P
+        kk = [(x + y + z) % P for x, y, z in zip(mat_vec(Mp2, k0, P), mat_vec(Mp, k1, P), k2)]
+        pad = lambda c: [c & M32, 0, c >> 32, 0]
+        out += [Mp2[0][i] for i in range(1, 12)] + [b[0]] + pad(ky0)          # record 0
+        out += pad(ky1) + a                                                    # record 1
+        out += b + [0, 0, 0, 0]                                                # record 2
+        for j in range(12):
+            out += [Mp3[j][i] for i in range(1, 12)] + [0] + pad(kk[j])       # output records
+    return out
+
+
+def fold_exact(al, ah, carry, e, dst):
+    """dst = al + ah phi, exact (see fold_group); al, ah, dst: register pairs (dst may be al); e: an (x, 0) pair."""
+    yield ("mad", vp(al), "vcc", v(ah + 1), -1, vp(al))
+    yield ("addco", v(al + 1), sp(carry), v(al + 1), v(ah))
+    yield ("cnd", v(e), 0, -1, sp(carry))
+    yield ("add64", vp(dst), vp(al), vp(e))
+
+
+def partial_block(p, src, dst, ratio=2):
+    M, Mp, Mp2, Mp3, m0, b, a = block_matrices()
+    C0, C1, C2 = SB_CONST, SB_CONST + 16, SB_CONST + 32          # three 16-dword scalar slots
+    AH = [TMP + 2 * j for j in range(12)]                        # high-digit sums of the 12 outputs; low-digit sums in dst
+    AL = [dst[j][0] for j in range(12)]
+    Y0L, Y0H, Y1L, Y1H = TMP + 24, TMP + 26, TMP + 28, TMP + 30
+    stream = N_STREAMS - 1
+    cfold = SB_CARRY                                             # carry pairs of the folds (streams 0, 1 are idle here)
+
+    def chain():   # the sequential part: three S-boxes and the two lane-0 values between them
+        yield from sbox_task(src[0], src[0][0], stream)                      # t0 in place of u0
+        yield ("await", "y0")
+        yield ("mad", vp(Y0L), "vcc", v(src[0][0]), m0[0], vp(Y0L))
+        yield ("mad", vp(Y0H), "vcc", v(src[0][1]), m0[0], vp(Y0H))
+        yield from fold_exact(Y0L, Y0H, cfold, E0, Y0L)
+        yield from sbox_task((Y0L, Y0L + 1), Y0L, stream)                    # t1 in place of y0
+        yield ("await", "y1")
+        yield ("mad", vp(Y1L), "vcc", v(src[0][0]), s1(C0 + 11), vp(Y1L))
+        yield ("mad", vp(Y1H), "vcc", v(src[0][1]), s1(C0 + 11), vp(Y1H))
+        yield ("mad", vp(Y1L), "vcc", v(Y0L), m0[0], vp(Y1L))
+        yield ("mad", vp(Y1H), "vcc", v(Y0L + 1), m0[0], vp(Y1H))
+        yield ("release", "c0")                                              # slot C0 may be overwritten from here on
+        yield from fold_exact(Y1L, Y1H, cfold + 2, E0 + 2, Y1L)
+        yield from sbox_task((Y1L, Y1L + 1), Y1L, stream)                    # t2 in place of y'0
+
+    def bulk():    # everything that does not depend on the S-boxes
+        for h, acc in ((0, Y0L), (1, Y0H)):
+            for i in range(1, 12):
+                yield ("mad", vp(acc), "vcc", v(src[i][h]), M[0][i], sp(C0 + 12 + 2 * h) if i == 1 else vp(acc))
+        yield ("mark", "y0")
+        # (one scalar operand per vector instruction: a scalar coefficient and a scalar initial value cannot share a multiply-add)
+        for h, acc in ((0, Y1L), (1, Y1H)):
+            yield ("mov64", vp(acc), sp(C1 + 2 * h))
+            for i in range(1, 12):
+                yield ("mad", vp(acc), "vcc", v(src[i][h]), s1(C0 + i - 1), vp(acc))
+        yield ("mark", "y1")
+        for j in range(12):
+            slot = C2 if j % 2 == 0 else C0
+            if j == 1:
+                yield ("need", "c0")                     # slot C0 still holds the lane-0 coefficient of y'0
+            if j >= 1:
+                yield ("s_load16_blk", slot, 64 * (3 + j))
+            yield ("s_waitcnt",)
+            if j == 0:
+                pass
+            for h, acc in ((0, AL[j]), (1, AH[j])):
+                yield ("mov64", vp(acc), sp(slot + 12 + 2 * h))
+            for i in range(1, 12):
+                for h, acc in ((0, AL[j]), (1, AH[j])):
+                    yield ("mad", vp(acc), "vcc", v(src[i][h]), s1(slot + i - 1), vp(acc))
+
+    # prologue: records 0, 1 and the first output record
+    p.emit("s_load16_blk", C0, 0)
+    p.emit("s_load16_blk", C1, 64)
+    p.emit("s_load16_blk", C2, 64 * 3)
+    p.emit("s_waitcnt")
+    ch, bk = chain(), bulk()
+    marks, released = set(), set()
+    ch_next = bk_next = None
+    ch_done = bk_done = False
+
+    def pull(g):
+        try:
+            return next(g)
+        except StopIteration:
+            return None
+
+    ch_next, bk_next = pull(ch), pull(bk)
+    while ch_next is not None or bk_next is not None:
+        # one instruction of the chain (if it is not waiting for the bulk)
+        if ch_next is not None:
+            if ch_next[0] == "await":
+                if ch_next[1] in marks:
+                    ch_next = pull(ch)
+                    continue
+            elif ch_next[0] == "release":
+                released.add(ch_next[1])
+                ch_next = pull(ch)
+                continue
+            else:
+                p.emit(*ch_next)
+                ch_next = pull(ch)
+        # `ratio` instructions of the bulk (if it is not waiting for the chain)
+        for _ in range(ratio):
+            if bk_next is None:
+                break
+            if bk_next[0] == "mark":
+                marks.add(bk_next[1])
+                bk_next = pull(bk)
+                continue
+            if bk_next[0] == "need":
+                if bk_next[1] in released:
+                    bk_next = pull(bk)
+                    continue
+                break
+            p.emit(*bk_next)
+            bk_next = pull(bk)
+    # the S-box outputs enter the twelve lanes; folds
+    p.emit("s_load16_blk", C0, 128)            # record 2: b
+    p.emit("s_waitcnt")
+    tk = [(src[0][0], src[0][1]), (Y0L, Y0L + 1), (Y1L, Y1L + 1)]
+
+    def tail(j):
+        coef = [s1(C1 + 4 + j), s1(C0 + j), m0[j]]
+        for k in range(3):
+            yield ("mad", vp(AL[j]), "vcc", v(tk[k][0]), coef[k], vp(AL[j]))
+            yield ("mad", vp(AH[j]), "vcc", v(tk[k][1]), coef[k], vp(AH[j]))
+        yield from fold_exact(AL[j], AH[j], cfold + 2 * (j % 4), E0 + 2 * (j % 2), AL[j])
+    for j0 in range(0, 12, 2):        # two at a time: there are two (e, 0) pairs
+        interleave(p, [tail(j) for j in range(j0, j0 + 2)])
+    p.emit("s_add_blk", BLK_BYTES)
+
+
 def permutation_body(p, tag=""):
     """30 rounds on bank A (round 0's constants already added); the table pointer S_PTR must point at INIT[0]."""
     p.emit("s_mov", S_HALF, 0)
@@ -321,11 +501,26 @@ def permutation_body(p, tag=""):
     p.emit("loop", S_CNT, "full" + tag)
     p.emit("s_branch_if_ne0", S_HALF, "done" + tag)
     rezero_stream_temps(p, [N_STREAMS - 1])
-    p.emit("s_mov", S_CNT, 11)
-    p.emit("label", "part" + tag)
-    partial_round(p, A, S)
-    partial_round(p, S, A)
-    p.emit("loop", S_CNT, "part" + tag)
+    if MODE["fast"] and "noblocks" not in EXPERIMENT:
+        # rounds 4..24 as seven blocks of three, round 25 alone
+        p.emit("s_waitcnt")                # the prefetch of the last full round must land before the slots are reused
+        p.emit("e_zero")
+        p.emit("s_mov", S_CNT, 3)
+        p.emit("label", "part" + tag)
+        partial_block(p, A, S)
+        partial_block(p, S, A)
+        p.emit("loop", S_CNT, "part" + tag)
+        partial_block(p, A, S)
+        p.emit("s_add_ptr", ROUND_BYTES * 21)
+        for k in range(3):
+            p.emit("s_load16", SB_CONST + 16 * k, 64 * k)
+        partial_round(p, S, A)
+    else:
+        p.emit("s_mov", S_CNT, 11)
+        p.emit("label", "part" + tag)
+        partial_round(p, A, S)
+        partial_round(p, S, A)
+        p.emit("loop", S_CNT, "part" + tag)
     p.emit("s_mov", S_HALF, 1)
     p.emit("s_branch", "half" + tag)
     p.emit("label", "done" + tag)
@@ -345,6 +540,7 @@ def build_permute():
     p.emit("copy_in")                      # v_mov_b64 of the 12 operands into bank A
     flags_init(p)
     p.emit("s_ptr", "tab")
+    p.emit("s_ptr_blk")
     MODE["fast"] = True
     permutation_body(p)
     p.emit("flagcheck", "ok")
@@ -399,6 +595,7 @@ def build_sponge():
     p.emit("lds_save")
     flags_init(p)
     p.emit("s_ptr", "tab")
+    p.emit("s_ptr_blk")
     MODE["fast"] = True
     permutation_body(p)
     p.emit("flagcheck", "next")
@@ -415,12 +612,12 @@ def build_sponge():
 
 
 # ---- hazards: a VALU instruction may read an SGPR written by a VALU instruction only 2 wait states later --------------------
-VALU = ("mad", "mov", "cnd", "sub", "add3", "min", "min3", "max3", "add64", "addco", "subco", "subbco", "cmplt64")
+VALU = ("mad", "mov", "mov64", "cnd", "sub", "add3", "min", "min3", "max3", "add64", "addco", "subco", "subbco", "cmplt64")
 
 
 def sgpr_reads(t):
     srcs = t[3:] if t[0] in ("mad", "addco", "subco", "subbco") else t[2:]
-    return [a[1] for a in srcs if isinstance(a, tuple) and a[0] == "sp"]
+    return [a[1] for a in srcs if isinstance(a, tuple) and a[0] in ("sp", "s")]
 
 
 def sgpr_write(t):
@@ -474,6 +671,7 @@ class Machine:
     def __init__(self):
         self.v = {}
         self.s = {}
+        self.pending = set()      # SGPRs written by a scalar load that no s_waitcnt has covered yet
 
     def rd(self, a):
         if isinstance(a, int):
@@ -484,7 +682,11 @@ class Machine:
         if k == "vp":
             return self.v[i] | (self.v[i + 1] << 32)
         if k == "sp":
+            assert i not in self.pending and i + 1 not in self.pending, "scalar load not waited for: s%d" % i
             return self.s[i] | (self.s[i + 1] << 32)
+        if k == "s":
+            assert i not in self.pending, "scalar load not waited for: s%d" % i
+            return self.s[i]
         raise ValueError(a)
 
     def wr(self, a, val):
@@ -505,6 +707,7 @@ def run(ins, mem, state, leaf=None, stats=None):
     m = Machine()
     labels = {t[1]: k for k, t in enumerate(ins) if t[0] == "label"}
     pc = steps = 0
+    blk_ptr = 0
     ptr = ("tab", 0)
     col = 0
     while pc < len(ins):
@@ -512,6 +715,8 @@ def run(ins, mem, state, leaf=None, stats=None):
         op = t[0]
         pc += 1
         steps += 1
+        if "ops" in stats:
+            stats["ops"][op] = stats["ops"].get(op, 0) + 1
         if op == "copy_in":
             for i, x in enumerate(state):
                 m.wr(vp(A[i][0]), x)
@@ -579,7 +784,7 @@ def run(ins, mem, state, leaf=None, stats=None):
             m.wr(t[1], m.rd(t[2]) & m.rd(t[3]))
         elif op == "cmplt64":
             m.wr(t[1], 1 if m.rd(t[2]) < m.rd(t[3]) else 0)
-        elif op == "mov":
+        elif op in ("mov", "mov64"):
             m.wr(t[1], m.rd(t[2]))
         elif op == "cnd":
             m.wr(t[1], m.rd(t[3]) if m.rd(t[4]) & 1 else m.rd(t[2]))
@@ -606,7 +811,19 @@ def run(ins, mem, state, leaf=None, stats=None):
             base = (ptr[1] + t[2]) // 4
             for k in range(n):
                 m.s[t[1] + k] = mem[ptr[0]][base + k]
-        elif op in ("s_waitcnt", "s_waitcnt_all", "label", "s_nop"):
+                m.pending.add(t[1] + k)
+        elif op == "s_load16_blk":
+            base = (blk_ptr + t[2]) // 4
+            for k in range(16):
+                m.s[t[1] + k] = mem["blk"][base + k]
+                m.pending.add(t[1] + k)
+        elif op == "s_add_blk":
+            blk_ptr += t[1]
+        elif op == "s_ptr_blk":
+            blk_ptr = 0
+        elif op in ("s_waitcnt", "s_waitcnt_all"):
+            m.pending.clear()
+        elif op in ("label", "s_nop"):
             pass
         elif op == "loop":
             m.s[t[1]] -= 1
@@ -630,7 +847,7 @@ def fmt(a):
     if a == "vcc":
         return "vcc"
     k, i = a
-    return {"v": "v%d" % i, "vp": "v[%d:%d]" % (i, i + 1), "sp": "s[%d:%d]" % (i, i + 1)}[k]
+    return {"v": "v%d" % i, "vp": "v[%d:%d]" % (i, i + 1), "sp": "s[%d:%d]" % (i, i + 1), "s": "s%d" % i}[k]
 
 
 def text(ins):
@@ -701,6 +918,8 @@ def text(ins):
             L.append("v_cmp_lt_u64 %s, %s, %s" % tuple(fmt(a) for a in t[1:]))
         elif op == "mov":
             L.append("v_mov_b32 %s, %s" % (fmt(t[1]), fmt(t[2])))
+        elif op == "mov64":
+            L.append("v_mov_b64 %s, %s" % (fmt(t[1]), fmt(t[2])))
         elif op == "cnd":
             L.append("v_cndmask_b32 %s, %s, %s, %s" % tuple(fmt(a) for a in t[1:]))
         elif op == "sub":
@@ -730,6 +949,13 @@ def text(ins):
             L.append("s_addc_u32 s%d, s%d, 0" % (S_PTR + 1, S_PTR + 1))
         elif op == "s_load16":
             L.append("s_load_dwordx16 s[%d:%d], s[%d:%d], 0x%x" % (t[1], t[1] + 15, S_PTR, S_PTR + 1, t[2]))
+        elif op == "s_load16_blk":
+            L.append("s_load_dwordx16 s[%d:%d], s[%d:%d], 0x%x" % (t[1], t[1] + 15, S_BLK, S_BLK + 1, t[2]))
+        elif op == "s_add_blk":
+            L.append("s_add_u32 s%d, s%d, %d" % (S_BLK, S_BLK, t[1]))
+            L.append("s_addc_u32 s%d, s%d, 0" % (S_BLK + 1, S_BLK + 1))
+        elif op == "s_ptr_blk":
+            L.append("s_mov_b64 s[%d:%d], %%[blk]" % (S_BLK, S_BLK + 1))
         elif op == "s_load8":
             L.append("s_load_dwordx8 s[%d:%d], s[%d:%d], 0x%x" % (t[1], t[1] + 7, S_PTR, S_PTR + 1, t[2]))
         elif op == "s_waitcnt":
@@ -756,7 +982,7 @@ def text(ins):
 
 # measured issue cost in cycles per wave instruction and SIMD (tools/ubench/sgpr_ops.hip): two classes; the full-rate ones
 # overlap with the half-rate ones of the same wave
-HALF = {"mad": 4.15, "cnd": 4.15, "add64": 4.15, "addco": 4.15, "subco": 4.15, "subbco": 4.15, "cmplt64": 4.15, "add3": 4.15,
+HALF = {"mov64": 4.15, "mad": 4.15, "cnd": 4.15, "add64": 4.15, "addco": 4.15, "subco": 4.15, "subbco": 4.15, "cmplt64": 4.15, "add3": 4.15,
         "min3": 4.15, "max3": 4.15}
 FULL = {"mov": 2.1, "sub": 2.1, "min": 2.1}
 UNIT = dict(HALF, **FULL)
@@ -791,7 +1017,7 @@ def main():
                                                                  "plonky2_bn254_amd", "csrc")
     rc = round_constants()
     tab = init_table(rc)
-    mem = {"tab": table_dwords(tab), "rc": [w for c in rc[:12] for w in (c & M32, c >> 32)]}
+    mem = {"tab": table_dwords(tab), "rc": [w for c in rc[:12] for w in (c & M32, c >> 32)], "blk": block_tables(tab)}
     if EXPERIMENT:
         ins = pad_hazards(build_permute().ins)
         with open(os.path.join(out_dir, "poseidon_asm_%s.inc" % EXPERIMENT.replace(",", "_")), "w") as f:
@@ -831,7 +1057,11 @@ def main():
             st[:len(leaf[c:c + 8])] = leaf[c:c + 8]
             st = permute(st, rc)
         assert [g % P for g in got[:4]] == st[:4], n
-    valu, half, cycles = dynamic_counts(perm)
+    st1 = {"ops": {}}
+    run(perm, mem, [(x + rc[i]) % P for i, x in enumerate(KATS[1][0])], stats=st1)
+    valu = sum(n for k, n in st1["ops"].items() if k in UNIT)
+    half = sum(n for k, n in st1["ops"].items() if k in HALF)
+    cycles = 4.15 * half + 3.6 * (valu - half)
     print("interpreter ok (%d instructions executed per permutation; exact repeats in the tests: %d of %d checks)" %
           (steps, stats.get("repeats", 0), stats.get("checks", 0)))
     print("fast code: %d VALU instructions per permutation, %d of them half-rate -> about %.0f cycles per wave and SIMD; "
@@ -850,12 +1080,18 @@ def main():
         write_macro(f, "POSEIDON_ASM_PERMUTE", text(perm))
         write_macro(f, "POSEIDON_ASM_SPONGE", text(sponge))
         f.write("#define POSEIDON_ASM_SPONGE_CLOBBERS " + ", ".join('"v%d"' % i for i in range(LD0, LD0 + 16)) + "\n")
-        clob = ['"v%d"' % i for i in range(VB, V_END)] + ['"s%d"' % i for i in list(range(SB_LOOP, SB_LOOP + 6)) + list(range(SB_CARRY, S_HALF + 1)) + [30, 31, 34, 35, 22, 23]] + ['"vcc"', '"scc"']
+        clob = ['"s%d"' % S_BLK, '"s%d"' % (S_BLK + 1)] + ['"v%d"' % i for i in range(VB, V_END)] + ['"s%d"' % i for i in list(range(SB_LOOP, SB_LOOP + 6)) + list(range(SB_CARRY, S_HALF + 1)) + [30, 31, 34, 35, 22, 23]] + ['"vcc"', '"scc"']
         f.write("#define POSEIDON_ASM_CLOBBERS " + ", ".join(clob) + "\n")
     with open(os.path.join(out_dir, "poseidon_init.inc"), "w") as f:
         f.write("/* Initial digit sums of the MDS layer of every round (tools/gen_poseidon_asm.py: init_table): per round and output\n"
                 "   lane four dwords (low 32 bits, 0, high 32 bits, 0) of the constant the layer adds; 31 rounds (the last is padding). */\n")
         d = mem["tab"]
+        for i in range(0, len(d), 8):
+            f.write("  " + ", ".join("0x%08xu" % x for x in d[i:i + 8]) + ",\n")
+    with open(os.path.join(out_dir, "poseidon_blocks.inc"), "w") as f:
+        f.write("/* Records of the merged partial-round blocks (tools/gen_poseidon_asm.py: block_tables): 7 blocks x 15 records x 16\n"
+                "   dwords - integer coefficients of row 0 of M'^2, of M'^3 and of the S-box output vectors, and the constants. */\n")
+        d = mem["blk"]
         for i in range(0, len(d), 8):
             f.write("  " + ", ".join("0x%08xu" % x for x in d[i:i + 8]) + ",\n")
     print("wrote poseidon_asm.inc (%d + %d lines), poseidon_init.inc (%d dwords)" % (len(text(perm)), len(text(sponge)), len(mem["tab"])))

@@ -15,7 +15,7 @@
                : [x0] "+v"(x[0]), [x1] "+v"(x[1]), [x2] "+v"(x[2]), [x3] "+v"(x[3]), [x4] "+v"(x[4]), [x5] "+v"(x[5]),      \
                  [x6] "+v"(x[6]), [x7] "+v"(x[7]), [x8] "+v"(x[8]), [x9] "+v"(x[9]), [x10] "+v"(x[10]), [x11] "+v"(x[11]),  \
                  [flag] "+v"(flag)                                                                                             \
-               : [tab] "s"(POSEIDON_INIT_DEV)                                                                                  \
+               : [tab] "s"(POSEIDON_INIT_DEV), [blk] "s"(POSEIDON_BLK_DEV)                                                     \
                : POSEIDON_ASM_CLOBBERS)
 
 template <int V>
