@@ -233,4 +233,20 @@ int bn254s_poseidon_permute(bn254s_ctx* c, uint64_t* states, size_t n) {
   return BN254S_OK;
 }
 
+// Debug: the hand-written gfx950 field sequences (csrc/gl_asm.h) on n operand pairs; out[n][17], see k_field_selftest.
+int bn254s_selftest_field(bn254s_ctx* c, const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out) {
+  if (!c || !a || !b || !out) return BN254S_E_INVALID_ARG;
+  if (n == 0) return BN254S_OK;
+  HIP_TRY(c, hipSetDevice(c->device));
+  u64* d = c->words("fs.io", (2 + FIELD_SELFTEST_OUTS) * n);
+  if (!d) return BN254S_E_OOM;
+  HIP_TRY(c, hipMemcpyAsync(d, a, 8 * n, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(d + n, b, 8 * n, hipMemcpyHostToDevice, c->stream));
+  field_selftest(d, d + n, d + 2 * n, n, c->stream);
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipMemcpyAsync(out, d + 2 * n, 8 * FIELD_SELFTEST_OUTS * n, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return BN254S_OK;
+}
+
 }  // extern "C"

@@ -59,13 +59,14 @@ struct bn254s_ctx : BufPool {
   // (doubling chain, upper Merkle levels, scans, PoW, FRI folds) run outside it and overlap freely.
   std::mutex big_mu;
   std::condition_variable big_cv;
-  // Weighted semaphore over the GPU-filling sections of all proofs in flight.  Classes (cost out of big_cap = 3):
-  //   BIG_NTT  (3): the NTT/LDE stage runs alone - it is the stage the roofline figure is quoted on;
-  //   BIG_EXCL (2): quotient, auxiliary columns, range-check histogram, openings, FRI combine - one at a time, but a
-  //                 leaf-hash launch may fill the SIMDs beside it;
-  //   BIG_HASH (1): Poseidon leaf hashing - one 2^17-leaf launch puts only two waves on a SIMD, up to three run together.
+  // Weighted semaphore over the GPU-filling sections of all proofs in flight.  Classes (cost out of big_cap = 6):
+  //   BIG_NTT  (6): the NTT/LDE stage runs alone - it is the stage the roofline figure is quoted on;
+  //   BIG_EXCL (3): quotient, auxiliary columns, range-check histogram, openings, FRI combine;
+  //   BIG_HASH (3): Poseidon leaf hashing - one 2^17-leaf launch puts two waves on a SIMD; two such sections run together
+  //                 (round 2 sweep with the hand-scheduled hash, tools/gpu_locksweep.sh: 70.1 proofs/s against 68.2 for the
+  //                 round-1 costs 3 / 2 / 1 out of 3 with six slots; letting the NTT stage share the GPU gives 71.2).
   // BN254S_BIG_CAP / BN254S_BIG_COST_NTT / BN254S_BIG_COST_EXCL / BN254S_BIG_COST_HASH override the costs (tuning only).
-  int big_cap = 3, big_cost[3] = {3, 2, 1}, big_used = 0;
+  int big_cap = 6, big_cost[3] = {6, 3, 3}, big_used = 0;
   void big_lock(int cls) {
     std::unique_lock<std::mutex> lk(big_mu);
     big_cv.wait(lk, [&] { return big_used + big_cost[cls] <= big_cap; });

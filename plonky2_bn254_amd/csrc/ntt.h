@@ -8,6 +8,7 @@ static constexpr size_t NTT_N = 65536;  // kernel transform size; trace height o
 struct NttTables {
   u64 *tw256_fwd = nullptr, *tw256_inv = nullptr;  // w_256^e
   u64 *twmat_fwd = nullptr, *twmat_inv = nullptr;  // w_N^(i2*k1) at [k1*256+i2]
+  u64* twmat_inv_ninv = nullptr;                   // (1/N) w_N^-(i2*k1)
   u64* coset_pow[2] = {nullptr, nullptr};          // shift_h^i
   u64* coset_inv_pow[2] = {nullptr, nullptr};      // (1/N) shift_h^-k
   u64 n_inv = 0;
@@ -41,3 +42,7 @@ void ntt_coset_inverse_tall(const NttTables* T, const NttTallTables* TT, int h, 
 void ntt_inverse_lde_tall(const NttTables* T, const NttTallTables* TT, const u64* values, u64* coeffs, u64* lde, u64* tmp, int ncols,
                           hipStream_t s);
 void ntt_lde_tall(const NttTables* T, const NttTallTables* TT, const u64* coeffs, u64* lde, u64* tmp, int ncols, hipStream_t s);
+
+// debug: runs the hand-written field sequences of gl_asm.h on n operand pairs (bn254s_selftest_field)
+static constexpr int FIELD_SELFTEST_OUTS = 17;
+void field_selftest(const u64* a, const u64* b, u64* out, size_t n, hipStream_t s);

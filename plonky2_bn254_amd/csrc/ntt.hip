@@ -17,6 +17,7 @@
 // no bit-reversal pass exist.  Global accesses are 128-byte segments (16 lanes x 8 B) or 16-byte
 // vectors; twiddle / coset tables have the same access pattern as the data and stay L2-resident.
 #include "gl_dev.h"
+#include "gl_asm.h"
 #include "ntt.h"
 
 // ---- radix-16 DFT in registers --------------------------------------------------------------------------
@@ -30,12 +31,19 @@ __device__ __forceinline__ u64 mul_w16(u64 x) {
 template <bool INV, int SPAN, int G, int J>
 __device__ __forceinline__ void bfly16(u64* x) {
   constexpr int E = J * (8 / SPAN);
-  constexpr int S = E == 0 ? 0 : (!INV ? 12 * E : 192 - 12 * E);  // twiddle = 2^S
-  u64 a = x[G + J], b = x[G + J + SPAN];
-  x[G + J] = gl_add(a, b);
-  // 2^96 = -1: a negative twiddle is folded into the subtraction (b - a) instead of a separate negation
-  if constexpr (S >= 96) x[G + J + SPAN] = gl_mul_2exp<S - 96>(gl_sub(b, a));
-  else x[G + J + SPAN] = gl_mul_2exp<S>(gl_sub(a, b));
+  constexpr int S0 = E == 0 ? 0 : (!INV ? 12 * E : 192 - 12 * E);  // twiddle = 2^S0
+  // 2^96 = -1: a negative twiddle is folded into the subtraction (b - a); 2^S with S > 64 is -2^-(96 - S), a Montgomery-style
+  // right shift (gl_asm.h) that is cheaper than three left shifts
+  constexpr bool NEG0 = S0 >= 96;
+  constexpr int S1 = NEG0 ? S0 - 96 : S0;
+  constexpr bool RIGHT = S1 > 64;
+  constexpr bool NEG = NEG0 != RIGHT;
+  u64 s, d;
+  gl_bfly_asm<NEG>(x[G + J], x[G + J + SPAN], s, d);
+  x[G + J] = s;
+  if constexpr (S1 == 0) x[G + J + SPAN] = d;
+  else if constexpr (RIGHT) x[G + J + SPAN] = gl_shr_small_asm<96 - S1>(d);
+  else x[G + J + SPAN] = gl_shl_asm<S1>(d);
 }
 // DIF network: natural-order input, output X[k] ends up in x[bitrev4(k)].
 template <bool INV>
@@ -56,29 +64,43 @@ __device__ __forceinline__ constexpr int br4(int x) { return ((x & 1) << 3) | ((
 //   0: lanes d-fast before and after (d = t&15)            slot = ka*272 + g*16 + d
 //   1: lanes g-fast before and after (g/ka = t&15)          slot = ka*257 + d*16 + g
 //   2: lanes g-fast before, d-fast after (re-maps d, ka)    slot = ka*272 + d*17 + g
-static constexpr int LDS_TILE_WORDS = 16 * 272;
+// The exchange moves the low and the high 32-bit words in two rounds through the same 17 KB image (slots are 4-byte
+// words, 64 banks): half the LDS of a one-round 64-bit exchange, so that eight workgroups fit on a CU and the loads of one
+// workgroup overlap the arithmetic of the others (the passes are neither HBM- nor VALU-bound alone).
+static constexpr int LDS_TILE_WORDS = 16 * 272;  // u32 words
 template <int MODE>
 __device__ __forceinline__ int lds_slot(int ka, int g, int d) {
   return MODE == 0 ? ka * 272 + g * 16 + d : MODE == 1 ? ka * 257 + d * 16 + g : ka * 272 + d * 17 + g;
 }
 template <bool INV, int MODE>
-__device__ __forceinline__ void dft256_tile(u64* x, u64* lds, const u64* __restrict__ tw256, int& d, int& g) {
+__device__ __forceinline__ void dft256_tile(u64* x, u32* lds, const u64* __restrict__ tw256, int& d, int& g) {
   dft16<INV>(x);
   // inner twiddle w_256^(g*ka), then transpose (g <-> ka) through LDS
 #pragma unroll
-  for (int ka = 0; ka < 16; ka++) {
-    u64 v = x[br4(ka)];
-    if (ka != 0) v = gl_mul(v, tw256[g * ka]);
-    lds[lds_slot<MODE>(ka, g, d)] = v;
-  }
-  __syncthreads();
+  for (int ka = 1; ka < 16; ka++) x[br4(ka)] = gl_mul_asm(x[br4(ka)], tw256[g * ka]);
+  int d2 = d, g2 = g;
   if (MODE == 2) {
-    d = threadIdx.x & 15;
-    g = threadIdx.x >> 4;
+    d2 = threadIdx.x & 15;
+    g2 = threadIdx.x >> 4;
   }
-  const int ka2 = g;  // the thread now owns (d, ka = g)
+  // MODE 1: the sixteen lanes of a 256-point transform sit in one wave (g = lane & 15) and a wave's four transforms own their
+  // slots, so the exchange needs no workgroup barrier: LDS operations of one wave complete in order.
+  u32 lo[16], hi[16];
 #pragma unroll
-  for (int gg = 0; gg < 16; gg++) x[gg] = lds[lds_slot<MODE>(ka2, gg, d)];
+  for (int ka = 0; ka < 16; ka++) lds[lds_slot<MODE>(ka, g, d)] = (u32)x[br4(ka)];
+  if (MODE == 1) __builtin_amdgcn_wave_barrier(); else __syncthreads();
+#pragma unroll
+  for (int gg = 0; gg < 16; gg++) lo[gg] = lds[lds_slot<MODE>(g2, gg, d2)];  // the thread now owns (d2, ka = g2)
+  if (MODE == 1) __builtin_amdgcn_wave_barrier(); else __syncthreads();
+#pragma unroll
+  for (int ka = 0; ka < 16; ka++) lds[lds_slot<MODE>(ka, g, d)] = (u32)(x[br4(ka)] >> 32);
+  if (MODE == 1) __builtin_amdgcn_wave_barrier(); else __syncthreads();
+#pragma unroll
+  for (int gg = 0; gg < 16; gg++) hi[gg] = lds[lds_slot<MODE>(g2, gg, d2)];
+#pragma unroll
+  for (int gg = 0; gg < 16; gg++) x[gg] = (u64)lo[gg] | ((u64)hi[gg] << 32);
+  d = d2;
+  g = g2;
   dft16<INV>(x);
 }
 
@@ -95,7 +117,7 @@ __global__ __launch_bounds__(256) void k_ntt_pass1(const u64* __restrict__ in, s
                                                    size_t out_stride, const u64* __restrict__ pre,
                                                    const u64* __restrict__ twmat, const u64* __restrict__ tw256,
                                                    unsigned log_r) {
-  __shared__ u64 lds[LDS_TILE_WORDS];
+  __shared__ u32 lds[LDS_TILE_WORDS];
   const int t = threadIdx.x;
   int d = t & 15, g = t >> 4;
   const int i2 = blockIdx.x * 16 + d;
@@ -105,7 +127,7 @@ __global__ __launch_bounds__(256) void k_ntt_pass1(const u64* __restrict__ in, s
   for (int m = 0; m < 16; m++) x[m] = col[(g + 16 * m) * 256 + i2];
   if (pre) {
 #pragma unroll
-    for (int m = 0; m < 16; m++) x[m] = gl_mul(x[m], pre[(g + 16 * m) * 256 + i2]);
+    for (int m = 0; m < 16; m++) x[m] = gl_mul_asm(x[m], pre[(g + 16 * m) * 256 + i2]);
   }
   dft256_tile<INV, 0>(x, lds, tw256, d, g);
   u64* ocol = out + col_offset(blockIdx.y, log_r, out_stride);
@@ -114,7 +136,7 @@ __global__ __launch_bounds__(256) void k_ntt_pass1(const u64* __restrict__ in, s
   for (int kb = 0; kb < 16; kb++) {
     int k1 = ka + 16 * kb;
     u64 v = x[br4(kb)];
-    v = gl_mul(v, twmat[k1 * 256 + i2]);
+    v = gl_mul_asm(v, twmat[k1 * 256 + i2]);
     ocol[k1 * 256 + i2] = v;
   }
 }
@@ -124,10 +146,10 @@ __global__ __launch_bounds__(256) void k_ntt_pass1(const u64* __restrict__ in, s
 // bit-reversed output order the 16 rows br8(k1) = br4(b)*16 + br4(d) form one contiguous 32 KB region.
 // post: optional per-output-index (natural k) scale table; post_scalar multiplies everything (1/N).
 template <bool INV, bool OUT_BITREV>
-__global__ __launch_bounds__(256) void k_ntt_pass2(const u64* __restrict__ in, size_t in_stride, u64* __restrict__ out,
+__global__ __launch_bounds__(256, 8) void k_ntt_pass2(const u64* __restrict__ in, size_t in_stride, u64* __restrict__ out,
                                                    size_t out_stride, const u64* __restrict__ post, u64 post_scalar,
                                                    const u64* __restrict__ tw256, unsigned log_r) {
-  __shared__ u64 lds[LDS_TILE_WORDS];
+  __shared__ u32 lds[LDS_TILE_WORDS];
   const int t = threadIdx.x;
   int g = t & 15, d = t >> 4;
   // bit-reversed output: rows k1 = b + 16 d (their images br8(k1) are 16 consecutive output rows);
@@ -149,8 +171,8 @@ __global__ __launch_bounds__(256) void k_ntt_pass2(const u64* __restrict__ in, s
     for (int p = 0; p < 16; p += 2) {
       u64 v0 = x[p], v1 = x[p + 1];
       if (post_scalar != 1) {
-        v0 = gl_mul(v0, post_scalar);
-        v1 = gl_mul(v1, post_scalar);
+        v0 = gl_mul_asm(v0, post_scalar);
+        v1 = gl_mul_asm(v1, post_scalar);
       }
       ulonglong2 w;
       w.x = v0;
@@ -162,8 +184,8 @@ __global__ __launch_bounds__(256) void k_ntt_pass2(const u64* __restrict__ in, s
     for (int kb = 0; kb < 16; kb++) {
       int k = k1 + 256 * (ka + 16 * kb);
       u64 v = x[br4(kb)];
-      if (post) v = gl_mul(v, post[k]);
-      else if (post_scalar != 1) v = gl_mul(v, post_scalar);
+      if (post) v = gl_mul_asm(v, post[k]);
+      else if (post_scalar != 1) v = gl_mul_asm(v, post_scalar);
       ocol[k] = v;
     }
   }
@@ -176,17 +198,18 @@ __global__ __launch_bounds__(256) void k_ntt_pass2(const u64* __restrict__ in, s
 // So the coefficients are stored once (they are kept for the openings) and the two coset transforms continue from registers:
 // the commitment moves 80 N bytes per column instead of 96 N and needs four launches instead of six.
 // grid = (16 tiles, ncols); y0 / y1 = pass-1 output of the cosets g and g*w_2N ([k1][i2] images for k_ntt_pass2).
-__global__ __launch_bounds__(256, 2) void k_ntt_intt2_lde1(const u64* __restrict__ in, size_t in_stride, u64* __restrict__ coef,
+__global__ __launch_bounds__(256, 3) void k_ntt_intt2_lde1(const u64* __restrict__ in, size_t in_stride, u64* __restrict__ coef,
                                                         size_t coef_stride, u64* __restrict__ y0, u64* __restrict__ y1,
-                                                        size_t y_stride, u64 n_inv, const u64* __restrict__ tw256_inv,
+                                                        size_t y_stride, const u64* __restrict__ tw256_inv,
                                                         const u64* __restrict__ pre0, const u64* __restrict__ pre1,
                                                         const u64* __restrict__ twmat, const u64* __restrict__ tw256_fwd,
                                                         unsigned log_r) {
-  __shared__ u64 lds[LDS_TILE_WORDS];
+  __shared__ u32 lds[LDS_TILE_WORDS];
+  u64 c[16];
   const int t = threadIdx.x;
   int g = t & 15, d = t >> 4;
   const u64* col = in + col_offset(blockIdx.y, log_r, in_stride);
-  u64 x[16], c[16];
+  u64 x[16];
   {
     const int k1_load = blockIdx.x * 16 + d;
 #pragma unroll
@@ -197,25 +220,26 @@ __global__ __launch_bounds__(256, 2) void k_ntt_intt2_lde1(const u64* __restrict
   u64* ocol = coef + col_offset(blockIdx.y, log_r, coef_stride);
 #pragma unroll
   for (int kb = 0; kb < 16; kb++) {
-    c[kb] = gl_mul(x[br4(kb)], n_inv);
+    c[kb] = x[br4(kb)];  // 1/N is already in the twiddle table of the pass before (twmat_inv_ninv)
     ocol[i2 + 256 * (g + 16 * kb)] = c[kb];
   }
 #pragma unroll 1
   for (int h = 0; h < 2; h++) {
     const u64* __restrict__ pre = h ? pre1 : pre0;
     u64* ycol = (h ? y1 : y0) + col_offset(blockIdx.y, log_r, y_stride);
+    asm volatile("" : "+v"(g), "+v"(d));  // the twiddle loads stay inside the loop (hoisted, they hold 62 registers)
 #pragma unroll
     for (int m = 0; m < 16; m++) {
-      x[m] = gl_mul(c[m], pre[(g + 16 * m) * 256 + i2]);
-      if ((m & 3) == 3) asm volatile("" ::: "memory");  // at most four table loads in flight: keeps the kernel free of spills
+      x[m] = gl_mul_asm(c[m], pre[(g + 16 * m) * 256 + i2]);
+      if ((m & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // four products at a time: operands of later ones are not loaded early
     }
     __syncthreads();  // the previous tile's LDS reads are done
     dft256_tile<false, 0>(x, lds, tw256_fwd, d, g);
 #pragma unroll
     for (int kb = 0; kb < 16; kb++) {
       int k1 = g + 16 * kb;
-      ycol[k1 * 256 + i2] = gl_mul(x[br4(kb)], twmat[k1 * 256 + i2]);
-      if ((kb & 3) == 3) asm volatile("" ::: "memory");
+      ycol[k1 * 256 + i2] = gl_mul_asm(x[br4(kb)], twmat[k1 * 256 + i2]);
+      if ((kb & 3) == 3) __builtin_amdgcn_sched_barrier(0);
     }
   }
 }
@@ -258,6 +282,11 @@ int ntt_tables_init(NttTables* T) {
       wk = gl_mul(wk, w);
     }
     if (upload(inv ? &T->twmat_inv : &T->twmat_fwd, h)) return -1;
+    if (inv) {  // (1/N) w_N^-(i2 k1): the fused from_values path folds the 1/N of the inverse transform into its first pass
+      const u64 ninv0 = gl_inv((u64)N);
+      for (auto& v : h) v = gl_mul(v, ninv0);
+      if (upload(&T->twmat_inv_ninv, h)) return -1;
+    }
   }
   // coset power tables: shift_h^i, shift_0 = g, shift_1 = g * w_2N
   u64 w2N = gl_root_of_unity(17);
@@ -278,6 +307,7 @@ void ntt_tables_free(NttTables* T) {
   hipFree(T->tw256_inv);
   hipFree(T->twmat_fwd);
   hipFree(T->twmat_inv);
+  hipFree(T->twmat_inv_ninv);
   for (int h = 0; h < 2; h++) {
     hipFree(T->coset_pow[h]);
     hipFree(T->coset_inv_pow[h]);
@@ -309,8 +339,8 @@ void ntt_inverse_lde(const NttTables* T, const u64* values, u64* coeffs, u64* ld
   dim3 grid(16, ncols), block(256);
   u64* y0 = tmp2;
   u64* y1 = tmp2 + (size_t)ncols * NTT_N;
-  k_ntt_pass1<true><<<grid, block, 0, s>>>(values, NTT_N, tmp, NTT_N, nullptr, T->twmat_inv, T->tw256_inv, 0);
-  k_ntt_intt2_lde1<<<grid, block, 0, s>>>(tmp, NTT_N, coeffs, NTT_N, y0, y1, NTT_N, T->n_inv, T->tw256_inv, T->coset_pow[0],
+  k_ntt_pass1<true><<<grid, block, 0, s>>>(values, NTT_N, tmp, NTT_N, nullptr, T->twmat_inv_ninv, T->tw256_inv, 0);
+  k_ntt_intt2_lde1<<<grid, block, 0, s>>>(tmp, NTT_N, coeffs, NTT_N, y0, y1, NTT_N, T->tw256_inv, T->coset_pow[0],
                                           T->coset_pow[1], T->twmat_fwd, T->tw256_fwd, 0);
   k_ntt_pass2<false, true><<<grid, block, 0, s>>>(y0, NTT_N, lde, 2 * NTT_N, nullptr, 1, T->tw256_fwd, 0);
   k_ntt_pass2<false, true><<<grid, block, 0, s>>>(y1, NTT_N, lde + NTT_N, 2 * NTT_N, nullptr, 1, T->tw256_fwd, 0);
@@ -570,8 +600,8 @@ void ntt_inverse_lde_tall(const NttTables* T, const NttTallTables* TT, const u64
     default: outer_inv_launch<6>(values, coeffs, N, TT, ncols, s); break;
   }
   dim3 grid(16, (unsigned)(ncols << log_r)), block(256);
-  k_ntt_pass1<true><<<grid, block, 0, s>>>(coeffs, N, tmp, N, nullptr, T->twmat_inv, T->tw256_inv, log_r);
-  k_ntt_intt2_lde1<<<grid, block, 0, s>>>(tmp, N, coeffs, N, lde, lde + N, 2 * N, T->n_inv, T->tw256_inv, TT->block_coset_pow[0],
+  k_ntt_pass1<true><<<grid, block, 0, s>>>(coeffs, N, tmp, N, nullptr, T->twmat_inv_ninv, T->tw256_inv, log_r);
+  k_ntt_intt2_lde1<<<grid, block, 0, s>>>(tmp, N, coeffs, N, lde, lde + N, 2 * N, T->tw256_inv, TT->block_coset_pow[0],
                                           TT->block_coset_pow[1], T->twmat_fwd, T->tw256_fwd, log_r);
   for (int h = 0; h < 2; h++) {
     u64* half = lde + (size_t)h * N;
@@ -604,6 +634,38 @@ void ntt_lde_tall(const NttTables* T, const NttTallTables* TT, const u64* coeffs
       default: outer_fwd_launch<6>(tmp, N, half, 2 * N, TT, h, ncols, s); break;
     }
   }
+}
+
+// ---- self test of the hand-written field sequences (gl_asm.h) -------------------------------------------------------
+// out[i][0..FIELD_SELFTEST_OUTS): a+b, a-b, b-a, a*b, then a 2^S for S in GL_SELFTEST_SHIFTS, then a 2^-K for K in GL_SELFTEST_RSHIFTS
+__global__ void k_field_selftest(const u64* __restrict__ a, const u64* __restrict__ b, u64* __restrict__ out, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const u64 x = a[i], y = b[i];
+  u64* o = out + i * FIELD_SELFTEST_OUTS;
+  u64 s, d, s2, d2;
+  gl_bfly_asm<false>(x, y, s, d);
+  gl_bfly_asm<true>(x, y, s2, d2);
+  o[0] = s;
+  o[1] = d;
+  o[2] = d2;
+  o[3] = s2 == s ? gl_mul_asm(x, y) : ~0ull;
+  o[4] = gl_shl_asm<12>(x);
+  o[5] = gl_shl_asm<24>(x);
+  o[6] = gl_shl_asm<32>(x);
+  o[7] = gl_shl_asm<36>(x);
+  o[8] = gl_shl_asm<48>(x);
+  o[9] = gl_shl_asm<60>(x);
+  o[10] = gl_shl_asm<64>(x);
+  o[11] = gl_shl_asm<1>(x);
+  o[12] = gl_shl_asm<31>(x);
+  o[13] = gl_shr_small_asm<12>(x);
+  o[14] = gl_shr_small_asm<24>(x);
+  o[15] = gl_shr_small_asm<1>(x);
+  o[16] = gl_shr_small_asm<31>(x);
+}
+void field_selftest(const u64* a, const u64* b, u64* out, size_t n, hipStream_t s) {
+  k_field_selftest<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(a, b, out, n);
 }
 
 // loads this translation unit's code object (the HIP runtime defers that to the first launch otherwise)

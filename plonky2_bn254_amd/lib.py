@@ -74,6 +74,7 @@ def load_library():
     lib.bn254s_commit_values.argtypes = [vp, vp, C.c_size_t, vp, vp, vp]
     lib.bn254s_bench_ntt.argtypes = [vp, C.c_size_t, C.c_int, C.POINTER(C.c_float)]
     lib.bn254s_poseidon_permute.argtypes = [vp, vp, C.c_size_t]
+    lib.bn254s_selftest_field.argtypes = [vp, vp, vp, C.c_size_t, vp]
     lib.bn254s_bench_copy.argtypes = [vp, C.c_size_t, C.c_int]
     lib.bn254s_bench_leafhash.argtypes = [vp, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_float)]
     lib.bn254s_g1_generate_trace.argtypes = [vp, vp, vp, vp, C.c_size_t, C.c_uint32, vp, vp]
@@ -267,6 +268,14 @@ class Context:
         ms = C.c_float()
         self._check(self._lib.bn254s_bench_leafhash(self._h, ncols, log_leaves, iters, C.byref(ms)), "bn254s_bench_leafhash")
         return ms.value
+
+    def selftest_field(self, a: np.ndarray, b: np.ndarray) -> np.ndarray:
+        """Debug: the hand-written field sequences (csrc/gl_asm.h) on operand pairs; returns out[n][17]."""
+        a = np.ascontiguousarray(a, dtype=np.uint64)
+        b = np.ascontiguousarray(b, dtype=np.uint64)
+        out = np.zeros((a.shape[0], 17), np.uint64)
+        self._check(self._lib.bn254s_selftest_field(self._h, _ptr(a), _ptr(b), a.shape[0], _ptr(out)), "bn254s_selftest_field")
+        return out
 
     def poseidon_permute(self, states: np.ndarray) -> np.ndarray:
         st = np.ascontiguousarray(states, dtype=np.uint64).copy()

@@ -52,3 +52,29 @@ def test_ntt_linearity_full_width(gpu_ctx):
     _, lb, _ = gpu_ctx.commit_values(b, want_coeffs=False)
     _, ls, _ = gpu_ctx.commit_values(s, want_coeffs=False)
     assert np.array_equal(((la.astype(object) + lb.astype(object)) % P).astype(np.uint64), ls)
+
+
+def test_field_asm_edge_cases(gpu_ctx):
+    """The hand-written gfx950 sequences of the NTT butterflies (csrc/gl_asm.h): sum, difference, product, multiplication by
+    2^S / 2^-K, against Python integers on boundary operands (0, 1, p-1, 2^32 +- 1, 2^64 - 2^32, words of all ones / zeros)
+    in every pairing, and on random operands."""
+    edge = [0, 1, 2, P - 1, P - 2, 2**32 - 1, 2**32, 2**32 + 1, 2**63, 2**63 - 1, P - 2**32, P - 2**32 - 1, P - 2**32 + 1,
+            2**64 - 2**33, 0xFFFFFFFF00000000, 0xFFFFFFFE00000001, 0xFFFFFFFEFFFFFFFF, 0x00000000FFFFFFFE, 0x0000000100000000,
+            0x8000000000000000, 0x7FFFFFFF80000000, 2**48, 2**48 - 1, 2**16, 0xFFFF0000FFFF0001, 0x0000FFFF00000000,
+            0x00000001FFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFE, 0x1000, 0xFFF, 0xFFFFFFFF00000000 - 1]
+    edge = sorted({e % P for e in edge})
+    rng = np.random.default_rng(5)
+    a = [x for x in edge for _ in edge] + [int(v) for v in rand_field(rng, 20000)]
+    b = [y for _ in edge for y in edge] + [int(v) for v in rand_field(rng, 20000)]
+    # sparse operands: few bits set, to reach the carry / borrow corners of the multi-word steps
+    for _ in range(20000):
+        a.append(sum(1 << int(k) for k in rng.integers(0, 64, size=rng.integers(1, 4))) % P)
+        b.append((P - sum(1 << int(k) for k in rng.integers(0, 64, size=rng.integers(1, 4)))) % P)
+    out = gpu_ctx.selftest_field(np.array(a, dtype=np.uint64), np.array(b, dtype=np.uint64))
+    shl = [12, 24, 32, 36, 48, 60, 64, 1, 31]
+    shr = [12, 24, 1, 31]
+    for i, (x, y) in enumerate(zip(a, b)):
+        exp = [(x + y) % P, (x - y) % P, (y - x) % P, x * y % P] + [x * pow(2, s, P) % P for s in shl] + \
+              [x * pow(2, 192 - k, P) % P for k in shr]
+        got = [int(v) for v in out[i]]
+        assert got == exp, (hex(x), hex(y), [j for j in range(17) if got[j] != exp[j]])
