@@ -99,6 +99,10 @@ void bn254s_ctx_destroy(bn254s_ctx* c) {
     ntt_tall_tables_free(kv.second);
     delete kv.second;
   }
+  for (auto& kv : c->split) {
+    ntt_split_tables_free(kv.second);
+    delete kv.second;
+  }
   c->release();
   ntt_tables_free(&c->ntt);
   hipStreamDestroy(c->stream);

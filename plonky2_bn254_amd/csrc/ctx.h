@@ -32,6 +32,12 @@ struct BufPool {
   }
   u64* words(const std::string& name, size_t n) { return (u64*)buf(name, n * 8); }
   bool has(const std::string& name) const { return pool.find(name) != pool.end(); }
+  void drop(const std::string& name) {
+    auto it = pool.find(name);
+    if (it == pool.end()) return;
+    hipFree(it->second.first);
+    pool.erase(it);
+  }
   void release() {
     for (auto& kv : pool) hipFree(kv.second.first);
     pool.clear();
@@ -54,7 +60,8 @@ struct bn254s_ctx : BufPool {
   hipStream_t stream = nullptr;
   NttTables ntt;
   std::vector<Slot*> slots;
-  std::map<unsigned, NttTallTables*> tall;  // per log_n
+  std::map<unsigned, NttTallTables*> tall;  // per log_n (+100: halves of a split transform)
+  std::map<unsigned, NttSplitTables*> split;  // per log_n
   // The GPU-filling sections of the proofs in flight take turns through the semaphore below; latency-bound kernels
   // (doubling chain, upper Merkle levels, scans, PoW, FRI folds) run outside it and overlap freely.
   std::mutex big_mu;

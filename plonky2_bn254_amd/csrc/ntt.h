@@ -32,7 +32,7 @@ struct NttTallTables {
   u64 shift[2] = {0, 0};                  // g, g*w_2N
   u64 r_inv = 0;
 };
-int ntt_tall_tables_init(NttTallTables* T, unsigned log_n);
+int ntt_tall_tables_init(NttTallTables* T, unsigned log_n, u64 base_shift = GL_GEN);
 void ntt_tall_tables_free(NttTallTables* T);
 // Coefficients live in the "transposed" layout: coefficient k1 + R*k2 at position k1*2^16 + k2.
 void ntt_inverse_tall(const NttTables* T, const NttTallTables* TT, const u64* values, u64* coeffs, u64* tmp, int ncols,
@@ -42,6 +42,20 @@ void ntt_coset_inverse_tall(const NttTables* T, const NttTallTables* TT, int h, 
 void ntt_inverse_lde_tall(const NttTables* T, const NttTallTables* TT, const u64* values, u64* coeffs, u64* lde, u64* tmp, int ncols,
                           hipStream_t s);
 void ntt_lde_tall(const NttTables* T, const NttTallTables* TT, const u64* coeffs, u64* lde, u64* tmp, int ncols, hipStream_t s);
+
+// ---- N = 2^23: one radix-2 level above the tall transforms (see ntt.hip) ---------------------------------------------
+struct NttSplitTables {
+  unsigned log_n = 0;
+  u64 *fwd_lo = nullptr, *fwd_hi = nullptr, *inv_lo = nullptr, *inv_hi = nullptr;  // w_N^(+-b), w_N^(+-2048 a)
+  u64 shift[2] = {0, 0};  // g, g*w_2N
+  u64 half = 0;
+};
+int ntt_split_tables_init(NttSplitTables* S, unsigned log_n);
+void ntt_split_tables_free(NttSplitTables* S);
+void ntt_split_inverse(const NttSplitTables* S, const u64* values, u64* halves, int ncols, hipStream_t s);
+void ntt_split_forward(const NttSplitTables* S, const u64* eo, u64* lde, size_t lde_stride, int ncols, hipStream_t s);
+void ntt_coset_inverse_split(const NttTables* T, const NttTallTables* TT, const NttSplitTables* S, int h, const u64* values, u64* coeffs,
+                             u64* tmp, int ncols, hipStream_t s);
 
 // debug: runs the hand-written field sequences of gl_asm.h on n operand pairs (bn254s_selftest_field)
 static constexpr int FIELD_SELFTEST_OUTS = 17;

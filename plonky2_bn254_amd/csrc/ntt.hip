@@ -513,7 +513,7 @@ __global__ __launch_bounds__(256) void k_coset_unscale(u64* __restrict__ c, size
   col[pos] = gl_mul(col[pos], gl_pow(shift_inv, k));
 }
 
-int ntt_tall_tables_init(NttTallTables* T, unsigned log_n) {
+int ntt_tall_tables_init(NttTallTables* T, unsigned log_n, u64 base_shift) {
   const unsigned log_r = log_n - 16;
   const size_t N = (size_t)1 << log_n, R = (size_t)1 << log_r;
   std::vector<u64> h;
@@ -534,8 +534,8 @@ int ntt_tall_tables_init(NttTallTables* T, unsigned log_n) {
     if (upload(&T->wn_pow_br, h)) return -1;
   }
   const u64 w2N = gl_root_of_unity(log_n + 1);
-  T->shift[0] = GL_GEN;
-  T->shift[1] = gl_mul(GL_GEN, w2N);
+  T->shift[0] = base_shift;
+  T->shift[1] = gl_mul(base_shift, w2N);
   for (int hh = 0; hh < 2; hh++) {
     fill_pow_table(h, gl_pow(T->shift[hh], R), NTT_N);  // (shift^R)^i2: coset of the block transforms
     if (upload(&T->block_coset_pow[hh], h)) return -1;
@@ -634,6 +634,98 @@ void ntt_lde_tall(const NttTables* T, const NttTallTables* TT, const u64* coeffs
       default: outer_fwd_launch<6>(tmp, N, half, 2 * N, TT, h, ncols, s); break;
     }
   }
+}
+
+// ---- one radix-2 level above the tall transforms: N = 2 H (2^23-row traces: H = 2^22) --------------------------------
+// P(x) = Pe(x^2) + x Po(x^2).  A column of N words holds the two halves [Pe | Po], each in the tall layout of an H-point
+// transform, so every tall routine above runs on "2 C columns of H words" unchanged:
+//   values -> halves:  Y0[p] = (x[p] + x[p+H]) / 2 = Pe(w_H^p),  Y1[p] = (x[p] - x[p+H]) w_N^-p / 2 = Po(w_H^p)      (in place)
+//   LDE: the point g w_2N^(2k+h) squares to (g^2 w_N^h) w_H^k, so the half transforms run on the cosets g^2, g^2 w_N (tall
+//   tables built with base shift g^2) and out[h N + 2q + {0,1}] = E[h H + q] +- t O[h H + q], t = g w_2N^h w_N^bitrev(q):
+//   w_2N^(2(k+H)+h) = -w_2N^(2k+h) and bitrev(k + H) = bitrev(k) + 1, the two results are neighbours.
+// w_N^e for e < 2^22 comes from two 2048-entry tables (e = 2048 a + b).
+__device__ __forceinline__ u64 split_pow(const u64* __restrict__ hi, const u64* __restrict__ lo, u32 e) {
+  return gl_mul(hi[e >> 11], lo[e & 2047]);
+}
+__global__ __launch_bounds__(256) void k_split_inv(const u64* __restrict__ in, u64* __restrict__ out, size_t N,
+                                                   const u64* __restrict__ hi, const u64* __restrict__ lo, u64 half, u64 odd_scale) {
+  const size_t H = N >> 1, p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const u64* x = in + (size_t)blockIdx.y * N;
+  u64* y = out + (size_t)blockIdx.y * N;
+  const u64 a = x[p], b = x[p + H];
+  y[p] = gl_mul(gl_add(a, b), half);
+  y[p + H] = gl_mul(gl_mul(gl_sub(a, b), split_pow(hi, lo, (u32)p)), odd_scale);  // odd_scale = 1/2 (or s^-1 / 2 on a coset)
+}
+__global__ __launch_bounds__(256) void k_split_fwd(const u64* __restrict__ eo, u64* __restrict__ out, size_t N, unsigned log_h,
+                                                   size_t out_stride, const u64* __restrict__ hi, const u64* __restrict__ lo, u64 shift0,
+                                                   u64 shift1) {
+  const size_t H = N >> 1, i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // i = h H + q < N
+  const u32 h = (u32)(i >> log_h), q = (u32)(i & (H - 1));
+  const u64* e = eo + (size_t)blockIdx.y * 2 * N;  // [E (N words) | O (N words)]: the LDEs of the two halves
+  const u32 k = bitrev32(q, log_h);
+  const u64 t = gl_mul(h ? shift1 : shift0, split_pow(hi, lo, k));
+  const u64 a = e[i], b = gl_mul(e[N + i], t);
+  ulonglong2 w;
+  w.x = gl_add(a, b);
+  w.y = gl_sub(a, b);
+  *reinterpret_cast<ulonglong2*>(out + (size_t)blockIdx.y * out_stride + (size_t)h * N + 2 * (size_t)q) = w;
+}
+// c[half][e] *= base^-e (e = k1 + R k2 in the tall layout): the unscaling of a coset interpolant whose halves hold q_(2e+par) s^(2e+par)
+__global__ __launch_bounds__(256) void k_coset_unscale_half(u64* __restrict__ c, size_t H, unsigned log_r, u64 base_inv) {
+  const size_t pos = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t k1 = pos >> 16, k2 = pos & (NTT_N - 1);
+  u64* col = c + (size_t)blockIdx.y * H;
+  col[pos] = gl_mul(col[pos], gl_pow(base_inv, k1 + (k2 << log_r)));
+}
+
+int ntt_split_tables_init(NttSplitTables* S, unsigned log_n) {
+  if (log_n < 18 || log_n > 23) return -1;  // e < 2^22 in split_pow
+  S->log_n = log_n;
+  const u64 w = gl_root_of_unity(log_n), wi = gl_inv(w);
+  std::vector<u64> h;
+  auto upload = [&](u64** dst) -> int {
+    if (hipMalloc((void**)dst, h.size() * 8) != hipSuccess) return -1;
+    return hipMemcpy(*dst, h.data(), h.size() * 8, hipMemcpyHostToDevice) == hipSuccess ? 0 : -1;
+  };
+  fill_pow_table(h, w, 2048);
+  if (upload(&S->fwd_lo)) return -1;
+  fill_pow_table(h, gl_pow(w, 2048), 2048);
+  if (upload(&S->fwd_hi)) return -1;
+  fill_pow_table(h, wi, 2048);
+  if (upload(&S->inv_lo)) return -1;
+  fill_pow_table(h, gl_pow(wi, 2048), 2048);
+  if (upload(&S->inv_hi)) return -1;
+  const u64 w2N = gl_root_of_unity(log_n + 1);
+  S->shift[0] = GL_GEN;
+  S->shift[1] = gl_mul(GL_GEN, w2N);
+  S->half = gl_inv(2);
+  return 0;
+}
+void ntt_split_tables_free(NttSplitTables* S) {
+  hipFree(S->fwd_lo);
+  hipFree(S->fwd_hi);
+  hipFree(S->inv_lo);
+  hipFree(S->inv_hi);
+}
+// values[C][N] -> halves (in place allowed); the caller then runs the tall routines on 2 C columns of H words
+void ntt_split_inverse(const NttSplitTables* S, const u64* values, u64* halves, int ncols, hipStream_t s) {
+  const size_t N = (size_t)1 << S->log_n;
+  k_split_inv<<<dim3((unsigned)(N / 512), ncols), 256, 0, s>>>(values, halves, N, S->inv_hi, S->inv_lo, S->half, S->half);
+}
+// eo[C][2][N] (bit-reversed LDEs of the two halves of each column) -> lde[C][2N] bit-reversed
+void ntt_split_forward(const NttSplitTables* S, const u64* eo, u64* lde, size_t lde_stride, int ncols, hipStream_t s) {
+  const size_t N = (size_t)1 << S->log_n;
+  k_split_fwd<<<dim3((unsigned)(N / 256), ncols), 256, 0, s>>>(eo, lde, N, S->log_n - 1, lde_stride, S->fwd_hi, S->fwd_lo, S->shift[0], S->shift[1]);
+}
+// values on coset h of the N-point domain (natural order) -> the halves of the interpolant's coefficients; TT = tall tables of H
+void ntt_coset_inverse_split(const NttTables* T, const NttTallTables* TT, const NttSplitTables* S, int h, const u64* values, u64* coeffs,
+                             u64* tmp, int ncols, hipStream_t s) {
+  const size_t N = (size_t)1 << S->log_n, H = N >> 1;
+  const u64 si = gl_inv(S->shift[h]);
+  // Q(s x) has coefficients q_k s^k: halves hold q_(2e) s^(2e) and q_(2e+1) s^(2e+1); the odd half's s^-1 rides on its 1/2
+  k_split_inv<<<dim3((unsigned)(N / 512), ncols), 256, 0, s>>>(values, coeffs, N, S->inv_hi, S->inv_lo, S->half, gl_mul(S->half, si));
+  ntt_inverse_tall(T, TT, coeffs, coeffs, tmp, 2 * ncols, s);
+  k_coset_unscale_half<<<dim3((unsigned)(H / 256), 2 * ncols), 256, 0, s>>>(coeffs, H, TT->log_n - 16, gl_mul(si, si));
 }
 
 // ---- self test of the hand-written field sequences (gl_asm.h) -------------------------------------------------------

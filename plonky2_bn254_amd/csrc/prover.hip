@@ -100,17 +100,32 @@ __global__ __launch_bounds__(256) void k_quotient_chunks(const u64* __restrict__
   } while (0)
 
 // Per-degree tables of the tall-trace NTT, built on first use.
-static const NttTallTables* get_tall_tables(bn254s_ctx* c, unsigned log_n) {
+// `half_of_split`: the tables of the H-point halves under the radix-2 level of ntt.hip (cosets g^2, g^2 w_2H instead of g, g w_2H)
+static const NttTallTables* get_tall_tables(bn254s_ctx* c, unsigned log_n, bool half_of_split = false) {
   static std::mutex mu;
   std::lock_guard<std::mutex> lk(mu);
-  auto it = c->tall.find(log_n);
+  const unsigned key = log_n + (half_of_split ? 100 : 0);
+  auto it = c->tall.find(key);
   if (it != c->tall.end()) return it->second;
   NttTallTables* t = new NttTallTables();
-  if (ntt_tall_tables_init(t, log_n) != 0) {
+  if (ntt_tall_tables_init(t, log_n, half_of_split ? gl_mul(GL_GEN, GL_GEN) : GL_GEN) != 0) {
     delete t;
     return nullptr;
   }
-  c->tall[log_n] = t;
+  c->tall[key] = t;
+  return t;
+}
+static const NttSplitTables* get_split_tables(bn254s_ctx* c, unsigned log_n) {
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lk(mu);
+  auto it = c->split.find(log_n);
+  if (it != c->split.end()) return it->second;
+  NttSplitTables* t = new NttSplitTables();
+  if (ntt_split_tables_init(t, log_n) != 0) {
+    delete t;
+    return nullptr;
+  }
+  c->split[log_n] = t;
   return t;
 }
 
@@ -152,8 +167,8 @@ static int prove_on_slot(bn254s_ctx* c, Slot& sl, int kind, const bn254s_params&
   const size_t N = rows_for(n, P.min_rows_log2);
   unsigned log_n = 0;
   while (((size_t)1 << log_n) < N) log_n++;
-  if (log_n < 16 || log_n > 22) {
-    err = "supported trace heights: 2^16 .. 2^22 rows (up to 8192 instances in one proof)";
+  if (log_n < 16 || log_n > 23) {
+    err = "supported trace heights: 2^16 .. 2^23 rows (up to 16384 instances in one proof)";
     return BN254S_E_UNSUPPORTED;
   }
   if (P.num_challenges != 2 || P.rate_bits != 1 || P.cap_height != 4 || P.arity_bits != 4 || P.min_rows_log2 < 16 ||
@@ -161,9 +176,16 @@ static int prove_on_slot(bn254s_ctx* c, Slot& sl, int kind, const bn254s_params&
     err = "unsupported StarkConfig (only standard_fast_config shapes)";
     return BN254S_E_UNSUPPORTED;
   }
-  const unsigned log_m2 = log_n + 1, log_r = log_n - 16;
+  // 2^23 rows: one radix-2 level above the tall transforms (ntt.hip), and the workspace is laid out to fit one GPU: the NTT
+  // stage runs in column chunks (its scratch is a chunk, not a commitment), the auxiliary coefficients overwrite their values,
+  // and the trace values are released before the auxiliary LDE is allocated.  BN254S_FORCE_SPLIT=1 takes
+  // the same path from 2^18 rows on (tests: word-for-word against the oracle at 2^18).
+  const bool force_split = getenv("BN254S_FORCE_SPLIT") && atoi(getenv("BN254S_FORCE_SPLIT"));  // read per call (tests)
+  const unsigned log_s = (log_n == 23 || (force_split && log_n >= 18)) ? 1 : 0;
+  const unsigned log_m2 = log_n + 1, log_r = log_n - 16 - log_s;
   const size_t R = (size_t)1 << log_r;
-  const size_t M2 = 2 * N;
+  const size_t M2 = 2 * N, NH = N >> log_s;  // NH: words of one half (= N without the extra level)
+  const int NSPL = 1 << log_s;              // coefficient arrays hold NSPL halves per polynomial
   const int W = sh.W, A = sh.n_aux(), NQ = 4, CAPW = 64;
   const int K = sh.n_total_constraints();
   hipStream_t st = sl.st;
@@ -175,24 +197,51 @@ static int prove_on_slot(bn254s_ctx* c, Slot& sl, int kind, const bn254s_params&
     return rc;
   }
   const NttTallTables* TT = nullptr;
+  const NttSplitTables* SP = nullptr;
   if (log_r) {
-    TT = get_tall_tables(c, log_n);
+    TT = get_tall_tables(c, log_n - log_s, log_s != 0);
     if (!TT) {
       err = "tall NTT tables";
       return BN254S_E_OOM;
     }
   }
+  if (log_s) {
+    SP = get_split_tables(c, log_n);
+    if (!SP) {
+      err = "split NTT tables";
+      return BN254S_E_OOM;
+    }
+  }
+  const int CH = 16;  // columns per chunk of the split commitment
   // iNTT / LDE / coset iNTT dispatch: 2^16-row traces use the four-step kernels directly, taller ones add the outer pass
   // from_values of a whole commitment: the fused four-launch form for 2^16 rows, iNTT then LDE otherwise
   auto do_commit_ntt = [&](const u64* vals, u64* coef, u64* lde, int nc) {
-    if (log_r) {
+    if (log_s) {
+      // per chunk: values -> [Pe | Po] (radix-2 level), the tall commitment of the 2 CH half columns, halves' LDEs -> LDE
+      u64* eo = d_tmp_fwd;                          // [CH][2][N]
+      u64* ntmp = d_tmp_fwd + (size_t)CH * 2 * N;   // [2 CH][NH]
+      for (int c0 = 0; c0 < nc; c0 += CH) {
+        const int cn = std::min(CH, nc - c0);
+        ntt_split_inverse(SP, vals + (size_t)c0 * N, coef + (size_t)c0 * N, cn, st);
+        ntt_inverse_lde_tall(&c->ntt, TT, coef + (size_t)c0 * N, coef + (size_t)c0 * N, eo, ntmp, 2 * cn, st);
+        ntt_split_forward(SP, eo, lde + (size_t)c0 * M2, M2, cn, st);
+      }
+    } else if (log_r) {
       ntt_inverse_lde_tall(&c->ntt, TT, vals, coef, lde, d_tmp_fwd, nc, st);
     } else {
       ntt_inverse_lde(&c->ntt, vals, coef, lde, d_tmp_fwd, d_tmp_fwd + (size_t)nc * N, nc, st);
     }
   };
   auto do_lde = [&](const u64* coef, u64* lde, int nc) {
-    if (log_r) ntt_lde_tall(&c->ntt, TT, coef, lde, d_tmp_fwd, nc, st);
+    if (log_s) {
+      u64* eo = d_tmp_fwd;
+      u64* ntmp = d_tmp_fwd + (size_t)CH * 2 * N;
+      for (int c0 = 0; c0 < nc; c0 += CH) {
+        const int cn = std::min(CH, nc - c0);
+        ntt_lde_tall(&c->ntt, TT, coef + (size_t)c0 * N, eo, ntmp, 2 * cn, st);
+        ntt_split_forward(SP, eo, lde + (size_t)c0 * M2, M2, cn, st);
+      }
+    } else if (log_r) ntt_lde_tall(&c->ntt, TT, coef, lde, d_tmp_fwd, nc, st);
     else ntt_lde(&c->ntt, coef, lde, d_tmp_fwd, nc, st);
   };
   const std::vector<int> arities = fri_arities(P, log_n);
@@ -202,22 +251,24 @@ static int prove_on_slot(bn254s_ctx* c, Slot& sl, int kind, const bn254s_params&
   // ---- workspace ------------------------------------------------------------------------------------------
   const size_t in_words = n * (4 + 2 * (size_t)PW);
   u64* d_in = mem.words("in", in_words + 16);
-  u64* d_tvals = mem.words("tvals", (size_t)W * N);
+  // split level: the trace values are dead once the auxiliary values exist, the auxiliary LDE takes their place
+  u64* d_tvals = mem.words("tvals", log_s ? std::max((size_t)W * N, (size_t)A * M2) : (size_t)W * N);
   u64* d_tcoef = mem.words("tcoef", (size_t)W * N);
   u64* d_hist = mem.words("hist", 65536 / 2);
-  u64* d_tmp = mem.words("tmp", (size_t)(log_r ? 1 : 3) * std::max(W, A) * N);  // [tmp | y0 | y1] for the fused commitment
+  // [tmp | y0 | y1] for the fused commitment; one tmp for a tall one; [E,O LDEs | tmp] of one column chunk under the split level
+  u64* d_tmp = mem.words("tmp", log_s ? (size_t)3 * CH * N : (size_t)(log_r ? 1 : 3) * std::max(W, A) * N);
   d_tmp_fwd = d_tmp;
   u64* d_tlde = mem.words("tlde", (size_t)W * M2);
   const size_t tree_words = merkle_tree_digests(log_m2, P.cap_height) * 4;
   u64* d_trees = mem.words("trees", 3 * tree_words);
   u64* d_avals = mem.words("avals", (size_t)A * N);
-  u64* d_acoef = mem.words("acoef", (size_t)A * N);
-  u64* d_alde = mem.words("alde", (size_t)A * M2);
+  u64* d_acoef = log_s ? d_avals : mem.words("acoef", (size_t)A * N);         // split level: the commitment runs in place
+  u64* d_alde = log_s ? d_tvals : mem.words("alde", (size_t)A * M2);
   const size_t trace_scr = kind == KIND_G1 ? g1_trace_scratch_words(n) : kind == KIND_G2 ? g2_trace_scratch_words(n) : fq_trace_scratch_words(n);
   u64* d_scr = mem.words("scratch", std::max(trace_scr, aux_scratch_words(sh, N)));
   u64* d_q = mem.words("quot", (size_t)(3 * NQ) * N + (size_t)NQ * M2 + (size_t)QUOTIENT_MAX_PARTS * 2 * M2);  // qv, ab, qcoef, qlde, partials
   u64* d_tabs = mem.words("tabs", 2 * (size_t)K + 10 * 2 * 80 + 4 * (size_t)(W + A + NQ));  // W, mzt, apow (8 u32 per power)
-  u64* d_open = mem.words("open", std::max((size_t)(W + A + NQ) * R * 5 + FRI_OPENING_TABLE_WORDS, n * (size_t)PW));
+  u64* d_open = mem.words("open", std::max((size_t)(W + A + NQ) * NSPL * R * 5 + FRI_OPENING_TABLE_WORDS, n * (size_t)PW));
   // FRI layer values (extension, 2 words) and trees
   size_t fri_words = 0, fri_tree_words = 0;
   {
@@ -241,7 +292,7 @@ static int prove_on_slot(bn254s_ctx* c, Slot& sl, int kind, const bn254s_params&
   }
   u64* d_qout = mem.words("qout", wpq * P.num_queries + 64);
   {  // pinned staging for the two larger device -> host copies (opening partials, query rounds), part of the workspace
-    const size_t need = std::max((size_t)(W + A + NQ) * R * 5, wpq * P.num_queries) * 8;
+    const size_t need = std::max((size_t)(W + A + NQ) * NSPL * R * 5, wpq * P.num_queries) * 8;
     if (sl.pinned_bytes < need) {
       if (sl.pinned) hipHostFree(sl.pinned);
       sl.pinned = nullptr;
@@ -392,7 +443,8 @@ static int prove_on_slot(bn254s_ctx* c, Slot& sl, int kind, const bn254s_params&
   }
   for (int a = 0; a < 2; a++)
     for (int h = 0; h < 2; h++)
-      if (log_r) ntt_coset_inverse_tall(&c->ntt, TT, h, d_qv + (size_t)(a * 2 + h) * N, d_ab + (size_t)(a * 2 + h) * N, d_tmp, 1, st);
+      if (log_s) ntt_coset_inverse_split(&c->ntt, TT, SP, h, d_qv + (size_t)(a * 2 + h) * N, d_ab + (size_t)(a * 2 + h) * N, d_tmp, 1, st);
+      else if (log_r) ntt_coset_inverse_tall(&c->ntt, TT, h, d_qv + (size_t)(a * 2 + h) * N, d_ab + (size_t)(a * 2 + h) * N, d_tmp, 1, st);
       else ntt_coset_inverse(&c->ntt, h, d_qv + (size_t)(a * 2 + h) * N, d_ab + (size_t)(a * 2 + h) * N, d_tmp, 1, st);
   {
     u64 gn = gl_pow(GL_GEN, N);
@@ -425,15 +477,16 @@ static int prove_on_slot(bn254s_ctx* c, Slot& sl, int kind, const bn254s_params&
   {
     BigSection big(c, st, BIG_EXCL);
     sb(ST_OPENINGS);
-    u64* d_otab = d_open + (size_t)(W + A + NQ) * R * 5;
-    fri_opening_tables(log_r, zeta, zeta_next, d_otab, st);
-    fri_openings(d_tcoef, N, log_r, W, d_otab, d_open, st);
-    fri_openings(d_acoef, N, log_r, A, d_otab, d_open + (size_t)W * R * 5, st);
-    fri_openings(d_qcoef, N, log_r, NQ, d_otab, d_open + (size_t)(W + A) * R * 5, st);
+    // split level: P(z) = Pe(z^2) + z Po(z^2), the halves are polynomials of NH coefficients opened at z^2 and (g z)^2
+    u64* d_otab = d_open + (size_t)(W + A + NQ) * NSPL * R * 5;
+    fri_opening_tables(log_r, log_s ? gl2_mul(zeta, zeta) : zeta, log_s ? gl2_mul(zeta_next, zeta_next) : zeta_next, d_otab, st);
+    fri_openings(d_tcoef, NH, log_r, W * NSPL, d_otab, d_open, st);
+    fri_openings(d_acoef, NH, log_r, A * NSPL, d_otab, d_open + (size_t)W * NSPL * R * 5, st);
+    fri_openings(d_qcoef, NH, log_r, NQ * NSPL, d_otab, d_open + (size_t)(W + A) * NSPL * R * 5, st);
   }
   // device -> host copies land in the slot's pinned staging buffer (pageable destinations go through a runtime-internal
   // staging allocation that costs ~8 ms the first time and an extra copy every time)
-  const size_t n_part = (size_t)(W + A + NQ) * R * 5, n_q = wpq * P.num_queries;
+  const size_t n_part = (size_t)(W + A + NQ) * NSPL * R * 5, n_q = wpq * P.num_queries;
   u64* h_part = (u64*)sl.pinned;
   std::vector<u64> h_open((size_t)(W + A + NQ) * 5);
   CHK(hipMemcpyAsync(h_part, d_open, n_part * 8, hipMemcpyDeviceToHost, st));
@@ -442,20 +495,26 @@ static int prove_on_slot(bn254s_ctx* c, Slot& sl, int kind, const bn254s_params&
   {  // P(z) = sum_k1 z^k1 S_k1(z^R) (transposed coefficient layout); P(1) = sum of the block sums
     std::vector<gl2> zp0(R), zp1(R);
     gl2 a = gl2_make(1, 0), b = gl2_make(1, 0);
+    const gl2 y0 = log_s ? gl2_mul(zeta, zeta) : zeta, y1 = log_s ? gl2_mul(zeta_next, zeta_next) : zeta_next;
     for (size_t k1 = 0; k1 < R; k1++) {
       zp0[k1] = a;
       zp1[k1] = b;
-      a = gl2_mul(a, zeta);
-      b = gl2_mul(b, zeta_next);
+      a = gl2_mul(a, y0);
+      b = gl2_mul(b, y1);
     }
     for (int p = 0; p < W + A + NQ; p++) {
       gl2 v0 = gl2_make(0, 0), v1 = gl2_make(0, 0);
       u64 s1 = 0;
-      for (size_t k1 = 0; k1 < R; k1++) {
-        const u64* q = &h_part[((size_t)p * R + k1) * 5];
-        v0 = gl2_add(v0, gl2_mul(zp0[k1], gl2_make(q[0], q[1])));
-        v1 = gl2_add(v1, gl2_mul(zp1[k1], gl2_make(q[2], q[3])));
-        s1 = gl_add(s1, q[4]);
+      for (int half = 0; half < NSPL; half++) {
+        gl2 e0 = gl2_make(0, 0), e1 = gl2_make(0, 0);
+        for (size_t k1 = 0; k1 < R; k1++) {
+          const u64* q = &h_part[(((size_t)p * NSPL + half) * R + k1) * 5];
+          e0 = gl2_add(e0, gl2_mul(zp0[k1], gl2_make(q[0], q[1])));
+          e1 = gl2_add(e1, gl2_mul(zp1[k1], gl2_make(q[2], q[3])));
+          s1 = gl_add(s1, q[4]);
+        }
+        v0 = gl2_add(v0, half ? gl2_mul(zeta, e0) : e0);
+        v1 = gl2_add(v1, half ? gl2_mul(zeta_next, e1) : e1);
       }
       u64* o5 = &h_open[(size_t)p * 5];
       o5[0] = v0.c0; o5[1] = v0.c1; o5[2] = v1.c0; o5[3] = v1.c1; o5[4] = s1;

@@ -22,6 +22,20 @@ def test_fq_exp_tall_proof_2pow18(gpu_ctx, oracle):
     assert rc == 0, msg
 
 
+def test_split_level_2pow18_matches_oracle(gpu_ctx, oracle, monkeypatch):
+    """The 2^23-row path (one radix-2 level above the tall transforms, chunked commitment, in-place auxiliary commitment,
+    halves opened at zeta^2) forced at 2^18 rows, where the oracle can still prove: every word of the proof."""
+    s, x = synth.fq_inputs(300, seed=33)
+    ref, ref_out, _, degree_bits = oracle_lib.prove(oracle, 2, s, x)
+    monkeypatch.setenv("BN254S_FORCE_SPLIT", "1")
+    pr = gpu_ctx.prove_fq_exp(s, x)
+    monkeypatch.delenv("BN254S_FORCE_SPLIT")
+    assert pr.degree_bits == 18 and pr.words.shape == ref.shape
+    bad = np.flatnonzero(pr.words != ref)
+    assert bad.size == 0, f"first differing words {bad[:5]} of {ref.size}"
+    assert np.array_equal(pr.outputs.reshape(-1, 4), ref_out)
+
+
 def test_g1_tall_proof_2pow17(gpu_ctx, oracle):
     s, x, o = synth.g1_inputs(150, seed=32)         # 76800 rows -> N = 2^17
     ref, ref_out, _, degree_bits = oracle_lib.prove(oracle, 0, s, x, o)
@@ -52,3 +66,24 @@ def test_fq_exp_very_tall_proofs_are_accepted_by_both_verifiers(gpu_ctx, oracle)
         bad[64 * 3 + 2 * 427 + 2 * 427 + 5] ^= np.uint64(1)  # an auxiliary opening
         rc, msg = oracle_lib.verify(oracle, 2, bad, bits, s, x)
         assert rc == 1 and "Mismatch" in msg
+
+
+def test_fq_exp_2pow23_rows_one_proof(gpu_ctx):
+    """16384 calls in ONE proof (N = 2^23, the size Bn254Hook::constrain would produce for BASELINE's 16384-call batch as a single
+    circuit): the radix-2 level above the tall transforms at its real size.  Checked by both of the library's verifiers (GPU
+    constraint sum and the independent host statement of the AIR); a corrupted opening is rejected."""
+    n = 16384
+    s, x = synth.fq_inputs(n, seed=63)
+    pr = gpu_ctx.prove_fq_exp(s, x)
+    assert pr.degree_bits == 23
+    for k in range(0, n, 1543):
+        assert synth.words_to_int(pr.outputs.reshape(-1, 4)[k]) == pow(synth.words_to_int(x[k]), synth.words_to_int(s[k]), synth.P)
+    import plonky2_bn254_amd as pk
+    gpu_ctx.verify(2, pr.words, 23, s, x, None, pr.outputs)
+    pk.verify_host(2, pr.words, 23, s, x, None, pr.outputs)
+    bad = pr.words.copy()
+    bad[64 * 3 + 2 * 427 + 2 * 427 + 5] ^= np.uint64(1)
+    with pytest.raises(pk.VerifyError):
+        gpu_ctx.verify(2, bad, 23, s, x, None, pr.outputs)
+    with pytest.raises(pk.VerifyError):
+        pk.verify_host(2, bad, 23, s, x, None, pr.outputs)

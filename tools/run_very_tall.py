@@ -1,4 +1,5 @@
-"""Very tall single proofs (N = 2^21, 2^22: R = 32 / 64 blocks per column): Fq-exp (light columns) and, optionally, G1.
+"""Very tall single proofs (N = 2^21, 2^22: R = 32 / 64 blocks per column; 2^23: the radix-2 level above them, 16384 instances):
+Fq-exp (light columns) and, optionally, G1.
 usage: python tools/run_very_tall.py [fq|g1] [log_rows=21]   Every proof is checked with bn254s_verify."""
 import sys
 import time
@@ -29,6 +30,7 @@ assert np.array_equal(pr.words, pr2.words)
 print(f"{kind} 2^{pr.degree_bits} rows, {n} instances: {1e3 * (t2 - t1):.0f} ms (first call {1e3 * (t1 - t0):.0f} ms), "
       f"{pr.words.size} proof words; stages", {a: round(b, 1) for a, b in pr.stage_ms.items()}, flush=True)
 ctx.verify(k, pr.words, pr.degree_bits, s, x, o, pr.outputs)
+pk.verify_host(k, pr.words, pr.degree_bits, s, x, o, pr.outputs)
 bad = pr.words.copy()
 bad[64 * 3 + 7] ^= np.uint64(1)
 try:
