@@ -145,11 +145,12 @@ __global__ __launch_bounds__(256) void k_ntt_pass1(const u64* __restrict__ in, s
 // grid = (16 tiles, ncols); block = 256.  Tile b handles rows k1 = b + 16*d (d = 0..15), so that in
 // bit-reversed output order the 16 rows br8(k1) = br4(b)*16 + br4(d) form one contiguous 32 KB region.
 // post: optional per-output-index (natural k) scale table; post_scalar multiplies everything (1/N).
+static constexpr int STAGE_ROW = 16 * 9;  // 16-byte units per staged output row: sixteen chunks of 8 pieces + 1 of padding
 template <bool INV, bool OUT_BITREV>
-__global__ __launch_bounds__(256, 8) void k_ntt_pass2(const u64* __restrict__ in, size_t in_stride, u64* __restrict__ out,
+__global__ __launch_bounds__(256, 4) void k_ntt_pass2(const u64* __restrict__ in, size_t in_stride, u64* __restrict__ out,
                                                    size_t out_stride, const u64* __restrict__ post, u64 post_scalar,
                                                    const u64* __restrict__ tw256, unsigned log_r) {
-  __shared__ u32 lds[LDS_TILE_WORDS];
+  __shared__ __attribute__((aligned(16))) u32 lds[OUT_BITREV ? 16 * STAGE_ROW * 4 : LDS_TILE_WORDS];  // exchange image, then the store staging
   const int t = threadIdx.x;
   int g = t & 15, d = t >> 4;
   // bit-reversed output: rows k1 = b + 16 d (their images br8(k1) are 16 consecutive output rows);
@@ -164,9 +165,13 @@ __global__ __launch_bounds__(256, 8) void k_ntt_pass2(const u64* __restrict__ in
   const int ka = g;
   u64* ocol = out + col_offset(blockIdx.y, log_r, out_stride);
   if (OUT_BITREV) {
-    // position = br8(k1)*256 + br8(k2), k2 = ka + 16*kb  ->  br4(ka)*16 + br4(kb): x[] is already in
-    // br4(kb) order, so the thread owns 16 consecutive words.
-    size_t base = (size_t)bitrev32(k1, 8) * 256 + br4(ka) * 16;
+    // position = br8(k1)*256 + br8(k2), k2 = ka + 16*kb  ->  br4(ka)*16 + br4(kb): x[] is already in br4(kb) order, so the
+    // thread owns 16 consecutive words (chunk br4(ka) of row br4(d) of the workgroup's 16 consecutive output rows).  Stored
+    // from there, a wave writes 64 separate 16-byte pieces per instruction and the lines reach HBM in parts (WRITE_SIZE 795
+    // MB for 648 MB, profiles/r02_pmc_ntt.md); staged through LDS, every store instruction of a wave is 1 KB contiguous.
+    __syncthreads();  // every wave is done with the exchange image (the staging image overlays it)
+    ulonglong2* stage = reinterpret_cast<ulonglong2*>(lds);
+    const int slot = br4(d) * STAGE_ROW + br4(ka) * 9;  // 16-byte units; chunk stride 144 B keeps the writes conflict free
 #pragma unroll
     for (int p = 0; p < 16; p += 2) {
       u64 v0 = x[p], v1 = x[p + 1];
@@ -177,7 +182,14 @@ __global__ __launch_bounds__(256, 8) void k_ntt_pass2(const u64* __restrict__ in
       ulonglong2 w;
       w.x = v0;
       w.y = v1;
-      *reinterpret_cast<ulonglong2*>(ocol + base + p) = w;
+      stage[slot + (p >> 1)] = w;
+    }
+    __syncthreads();
+    ulonglong2* o16 = reinterpret_cast<ulonglong2*>(ocol + (size_t)br4(blockIdx.x) * 16 * 256);
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const int piece = i * 256 + t;  // row = piece >> 7, chunk = (piece >> 3) & 15, part = piece & 7
+      o16[piece] = stage[(piece >> 7) * STAGE_ROW + ((piece >> 3) & 15) * 9 + (piece & 7)];
     }
   } else {
 #pragma unroll

@@ -4,14 +4,10 @@ cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 mkdir -p gpurun_out/nttchk
 python -m pytest tests/test_gpu_kernels.py -x -q -m gpu 2>&1 | tail -5
-for v in ${VARIANTS:-0}; do
-echo "== BN254S_NTT_PARK=$v"
-export BN254S_NTT_PARK=$v
-python tools/pmc_ntt.py
-rocprofv3 --kernel-trace --stats -d gpurun_out/nttchk -o ntt$v --output-format csv -- python3 tools/pmc_ntt.py > gpurun_out/nttchk/run.log 2>&1
+python tools/bench_ntt_iters.py
+rocprofv3 --kernel-trace --stats -d gpurun_out/nttchk -o ntt --output-format csv -- python3 tools/pmc_ntt.py 30 > gpurun_out/nttchk/run.log 2>&1
 python3 - <<PY
 import csv
-for r in csv.DictReader(open("gpurun_out/nttchk/ntt${v}_kernel_stats.csv")):
+for r in csv.DictReader(open("gpurun_out/nttchk/ntt_kernel_stats.csv")):
     if "ntt" in r["Name"] or "copy_u64" in r["Name"]: print(r["Name"][:70], r["Calls"], "avg us %.1f" % (float(r["AverageNs"]) / 1e3))
 PY
-done
