@@ -210,13 +210,18 @@ __global__ __launch_bounds__(256, 4) void k_ntt_pass2(const u64* __restrict__ in
 // So the coefficients are stored once (they are kept for the openings) and the two coset transforms continue from registers:
 // the commitment moves 80 N bytes per column instead of 96 N and needs four launches instead of six.
 // grid = (16 tiles, ncols); y0 / y1 = pass-1 output of the cosets g and g*w_2N ([k1][i2] images for k_ntt_pass2).
-__global__ __launch_bounds__(256, 3) void k_ntt_intt2_lde1(const u64* __restrict__ in, size_t in_stride, u64* __restrict__ coef,
+template <int NPARK>
+__global__ __launch_bounds__(256, NPARK ? 4 : 3) void k_ntt_intt2_lde1(const u64* __restrict__ in, size_t in_stride, u64* __restrict__ coef,
                                                         size_t coef_stride, u64* __restrict__ y0, u64* __restrict__ y1,
                                                         size_t y_stride, const u64* __restrict__ tw256_inv,
                                                         const u64* __restrict__ pre0, const u64* __restrict__ pre1,
                                                         const u64* __restrict__ twmat, const u64* __restrict__ tw256_fwd,
                                                         unsigned log_r) {
   __shared__ u32 lds[LDS_TILE_WORDS];
+  // NPARK of the thread's sixteen coefficients wait in LDS between the two coset transforms: with 8 of them there the kernel
+  // needs 122 registers and 33 KB of LDS, four workgroups per CU (1.76 ms per 1237-column stage against 1.84 ms with all
+  // sixteen in registers and three workgroups)
+  __shared__ u64 park[NPARK ? NPARK * 256 : 1];
   u64 c[16];
   const int t = threadIdx.x;
   int g = t & 15, d = t >> 4;
@@ -234,6 +239,7 @@ __global__ __launch_bounds__(256, 3) void k_ntt_intt2_lde1(const u64* __restrict
   for (int kb = 0; kb < 16; kb++) {
     c[kb] = x[br4(kb)];  // 1/N is already in the twiddle table of the pass before (twmat_inv_ninv)
     ocol[i2 + 256 * (g + 16 * kb)] = c[kb];
+    if (kb >= 16 - NPARK) park[(kb - (16 - NPARK)) * 256 + t] = c[kb];
   }
 #pragma unroll 1
   for (int h = 0; h < 2; h++) {
@@ -242,7 +248,7 @@ __global__ __launch_bounds__(256, 3) void k_ntt_intt2_lde1(const u64* __restrict
     asm volatile("" : "+v"(g), "+v"(d));  // the twiddle loads stay inside the loop (hoisted, they hold 62 registers)
 #pragma unroll
     for (int m = 0; m < 16; m++) {
-      x[m] = gl_mul_asm(c[m], pre[(g + 16 * m) * 256 + i2]);
+      x[m] = gl_mul_asm(m >= 16 - NPARK ? park[(m - (16 - NPARK)) * 256 + t] : c[m], pre[(g + 16 * m) * 256 + i2]);
       if ((m & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // four products at a time: operands of later ones are not loaded early
     }
     __syncthreads();  // the previous tile's LDS reads are done
@@ -352,7 +358,7 @@ void ntt_inverse_lde(const NttTables* T, const u64* values, u64* coeffs, u64* ld
   u64* y0 = tmp2;
   u64* y1 = tmp2 + (size_t)ncols * NTT_N;
   k_ntt_pass1<true><<<grid, block, 0, s>>>(values, NTT_N, tmp, NTT_N, nullptr, T->twmat_inv_ninv, T->tw256_inv, 0);
-  k_ntt_intt2_lde1<<<grid, block, 0, s>>>(tmp, NTT_N, coeffs, NTT_N, y0, y1, NTT_N, T->tw256_inv, T->coset_pow[0],
+  k_ntt_intt2_lde1<8><<<grid, block, 0, s>>>(tmp, NTT_N, coeffs, NTT_N, y0, y1, NTT_N, T->tw256_inv, T->coset_pow[0],
                                           T->coset_pow[1], T->twmat_fwd, T->tw256_fwd, 0);
   k_ntt_pass2<false, true><<<grid, block, 0, s>>>(y0, NTT_N, lde, 2 * NTT_N, nullptr, 1, T->tw256_fwd, 0);
   k_ntt_pass2<false, true><<<grid, block, 0, s>>>(y1, NTT_N, lde + NTT_N, 2 * NTT_N, nullptr, 1, T->tw256_fwd, 0);
@@ -613,7 +619,7 @@ void ntt_inverse_lde_tall(const NttTables* T, const NttTallTables* TT, const u64
   }
   dim3 grid(16, (unsigned)(ncols << log_r)), block(256);
   k_ntt_pass1<true><<<grid, block, 0, s>>>(coeffs, N, tmp, N, nullptr, T->twmat_inv_ninv, T->tw256_inv, log_r);
-  k_ntt_intt2_lde1<<<grid, block, 0, s>>>(tmp, N, coeffs, N, lde, lde + N, 2 * N, T->tw256_inv, TT->block_coset_pow[0],
+  k_ntt_intt2_lde1<8><<<grid, block, 0, s>>>(tmp, N, coeffs, N, lde, lde + N, 2 * N, T->tw256_inv, TT->block_coset_pow[0],
                                           TT->block_coset_pow[1], T->twmat_fwd, T->tw256_fwd, log_r);
   for (int h = 0; h < 2; h++) {
     u64* half = lde + (size_t)h * N;
