@@ -226,7 +226,7 @@ def run_g1(args, pk, torch, synth, ctx, rank, world, dist, device, gather_device
     ntt_ms = stage_ms.get("trace_ntt", 0.0) + stage_ms.get("aux_ntt", 0.0)
     ntt_bytes = NTT_BYTES_PER_COL * (W + A)
     achieved = ntt_bytes / (ntt_ms * 1e-3) / 1e9 if ntt_ms > 0 else 0.0
-    excl_ms = ctx.bench_ntt(W + A, 5)       # the same stage alone on the GPU (no other stream), after the timed region
+    excl_ms = ctx.bench_ntt(W + A, 20)      # the same stage alone on the GPU (no other stream), after the timed region
     excl = ntt_bytes / (excl_ms * 1e-3) / 1e9
     pmc, pmc_src = latest_profile("r*_pmc_ntt.json")
     traffic = int(pmc["ntt_stage_traffic_bytes_per_1237_cols"]) if pmc else None
