@@ -20,8 +20,8 @@ __device__ __forceinline__ u64 econv_c1(const u64* x0, const u64* x1, const u64*
   return gl_add(conv16(x0, y1, i), conv16(x1, y0, i));
 }
 
-#define MZB(blk, auxcol, FILTER, ...) \
-  mz_block(tl, M2, j, (auxcol), W0 + G2_MZ_E0[blk], W1 + G2_MZ_E0[blk], A.mzt + (blk) * 160, A.mzt + (blk) * 160 + 80, (FILTER), __VA_ARGS__, tot0, tot1)
+#define MZB(blk, auxcol, FILTER, FN, ...) \
+  mz_block(tl, M2, j, (auxcol), W0 + G2_MZ_E0[blk], W1 + G2_MZ_E0[blk], A.mzt + (blk) * 160, A.mzt + (blk) * 160 + 80, (FILTER), FN, tot0, tot1, ##__VA_ARGS__)
 
 __global__ __launch_bounds__(256) void k_quotient_g2_sched(QArgs A) {
   const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -45,10 +45,14 @@ __global__ __launch_bounds__(256, 2) void k_quotient_g2_add(QArgs A) {
   const u64 filter = TL(L::FILTER);
   const int AUX = L::AUX;
   const u64 is_x_eq_filter = TL(AUX + G2_AUX_IS_X_EQ_FILTER);
-  u64 ax0[16], ax1[16], dx0[16], dx1[16], t0[16], t1[16];
-  ld16(tl, M2, j, L::A, ax0);
-  ld16(tl, M2, j, L::A + 16, ax1);
+  // An eval_modulus_zero block is linear in its input polynomial, so the terms that are plain trace columns (b.y - a.y, the
+  // x coordinates, ...) are summed into the block's accumulator first, one value at a time; only the operands of the Fq2 limb
+  // products are ever held as arrays (four of them: 128 registers).  Round 1 held up to eight arrays and spilled.
+  auto seed_w = [&](Acc2& sd, int blk, int i, u64 v) { acc2_mad(sd, v, W0[G2_MZ_E0[blk] + 1 + i], W1[G2_MZ_E0[blk] + 1 + i]); };
   if constexpr (part == 0) {
+    u64 ax0[16], ax1[16], dx0[16], dx1[16], t0[16];
+    ld16(tl, M2, j, L::A, ax0);
+    ld16(tl, M2, j, L::A + 16, ax1);
     const u64 is_x_eq = TL(AUX + G2_AUX_IS_X_EQ), z0 = TL(AUX + G2_AUX_IS_C0_ZERO), z1 = TL(AUX + G2_AUX_IS_C1_ZERO);
     EMIT(gl_mul(filter, gl_sub(gl_mul(z0, z1), is_x_eq)));  // e = 0
     ld16(tl, M2, j, L::B, dx0);
@@ -87,89 +91,79 @@ __global__ __launch_bounds__(256, 2) void k_quotient_g2_add(QArgs A) {
     e = 99;
     EMIT(gl_sub(gl_mul(filter, is_x_eq), is_x_eq_filter));
   } else {
-    u64 l0[16], l1[16];
-    ld16(tl, M2, j, AUX + G2_AUX_LAMBDA, l0);
-    ld16(tl, M2, j, AUX + G2_AUX_LAMBDA + 16, l1);
+    Acc2 sd0, sd1;
+    acc2_init(sd0);
+    acc2_init(sd1);
+    u64 l0[16], l1[16], dx0[16], dx1[16];
     if constexpr (part == 1) {
       // lambda * delta_x - (b.y - a.y) under filter - is_x_eq_filter
-      ld16(tl, M2, j, L::B, dx0);
-      ld16(tl, M2, j, L::B + 16, dx1);
+#pragma unroll 4
+      for (int i = 0; i < 16; i++) {
+        seed_w(sd0, 2, i, gl_sub(TL(L::A + 32 + i), TL(L::B + 32 + i)));
+        seed_w(sd1, 3, i, gl_sub(TL(L::A + 48 + i), TL(L::B + 48 + i)));
+      }
+      ld16(tl, M2, j, AUX + G2_AUX_LAMBDA, l0);
+      ld16(tl, M2, j, AUX + G2_AUX_LAMBDA + 16, l1);
 #pragma unroll
       for (int i = 0; i < 16; i++) {
-        dx0[i] = gl_sub(dx0[i], ax0[i]);
-        dx1[i] = gl_sub(dx1[i], ax1[i]);
+        dx0[i] = gl_sub(TL(L::B + i), TL(L::A + i));
+        dx1[i] = gl_sub(TL(L::B + 16 + i), TL(L::A + 16 + i));
       }
-      ld16(tl, M2, j, L::B + 32, t0);
-      ld16(tl, M2, j, L::B + 48, t1);
-      ld16(tl, M2, j, L::A + 32, ax0);  // a.y (a.x no longer needed)
-      ld16(tl, M2, j, L::A + 48, ax1);
       const u64 f_ne = gl_sub(filter, is_x_eq_filter);
-      MZB(2, AUX + G2_AUX_LAMBDA_AUX, f_ne, [&](int i) {
-        u64 v = econv_c0(l0, l1, dx0, dx1, i);
-        return i < 16 ? gl_sub(v, gl_sub(t0[i < 16 ? i : 0], ax0[i < 16 ? i : 0])) : v;
-      });
-      MZB(3, AUX + G2_AUX_LAMBDA_AUX + 80, f_ne, [&](int i) {
-        u64 v = econv_c1(l0, l1, dx0, dx1, i);
-        return i < 16 ? gl_sub(v, gl_sub(t1[i < 16 ? i : 0], ax1[i < 16 ? i : 0])) : v;
-      });
+      MZB(2, AUX + G2_AUX_LAMBDA_AUX, f_ne, [&](int i) { return econv_c0(l0, l1, dx0, dx1, i); }, &sd0);
+      MZB(3, AUX + G2_AUX_LAMBDA_AUX + 80, f_ne, [&](int i) { return econv_c1(l0, l1, dx0, dx1, i); }, &sd1);
     } else if constexpr (part == 2) {
       // 2 * lambda * a.y - 3 * a.x^2 under is_x_eq_filter, then a.y == b.y
+      ld16(tl, M2, j, L::A, dx0);  // a.x: its squares go into the seeds, then the arrays are reused for a.y
+      ld16(tl, M2, j, L::A + 16, dx1);
+#pragma unroll
+      for (int i = 0; i < 31; i++) {
+        const u64 xx0 = econv_c0(dx0, dx1, dx0, dx1, i), xx1 = econv_c1(dx0, dx1, dx0, dx1, i);
+        seed_w(sd0, 4, i, gl_neg(gl_add(gl_dbl(xx0), xx0)));
+        seed_w(sd1, 5, i, gl_neg(gl_add(gl_dbl(xx1), xx1)));
+      }
+      ld16(tl, M2, j, AUX + G2_AUX_LAMBDA, l0);
+      ld16(tl, M2, j, AUX + G2_AUX_LAMBDA + 16, l1);
       ld16(tl, M2, j, L::A + 32, dx0);  // a.y
       ld16(tl, M2, j, L::A + 48, dx1);
-      MZB(4, AUX + G2_AUX_LAMBDA_AUX, is_x_eq_filter, [&](int i) {
-        u64 ly = econv_c0(l0, l1, dx0, dx1, i), xx = econv_c0(ax0, ax1, ax0, ax1, i);
-        return gl_sub(gl_dbl(ly), gl_add(gl_dbl(xx), xx));
-      });
-      MZB(5, AUX + G2_AUX_LAMBDA_AUX + 80, is_x_eq_filter, [&](int i) {
-        u64 ly = econv_c1(l0, l1, dx0, dx1, i), xx = econv_c1(ax0, ax1, ax0, ax1, i);
-        return gl_sub(gl_dbl(ly), gl_add(gl_dbl(xx), xx));
-      });
+      MZB(4, AUX + G2_AUX_LAMBDA_AUX, is_x_eq_filter, [&](int i) { return gl_dbl(econv_c0(l0, l1, dx0, dx1, i)); }, &sd0);
+      MZB(5, AUX + G2_AUX_LAMBDA_AUX + 80, is_x_eq_filter, [&](int i) { return gl_dbl(econv_c1(l0, l1, dx0, dx1, i)); }, &sd1);
       e = 232;
-      ld16(tl, M2, j, L::B + 32, t0);
-      ld16(tl, M2, j, L::B + 48, t1);
       Acc2 g;
       acc2_init(g);
 #pragma unroll
-      for (int i = 0; i < 16; i++) acc2_mad(g, gl_sub(dx0[i], t0[i]), W0[e + i], W1[e + i]);
+      for (int i = 0; i < 16; i++) acc2_mad(g, gl_sub(dx0[i], TL(L::B + 32 + i)), W0[e + i], W1[e + i]);
 #pragma unroll
-      for (int i = 0; i < 16; i++) acc2_mad(g, gl_sub(dx1[i], t1[i]), W0[e + 16 + i], W1[e + 16 + i]);
+      for (int i = 0; i < 16; i++) acc2_mad(g, gl_sub(dx1[i], TL(L::B + 48 + i)), W0[e + 16 + i], W1[e + 16 + i]);
       tot0 = gl_add(tot0, gl_mul(is_x_eq_filter, acc_red(g.a0)));
       tot1 = gl_add(tot1, gl_mul(is_x_eq_filter, acc_red(g.a1)));
     } else if constexpr (part == 3) {
       // lambda^2 - (a.x + b.x + c.x)
-      ld16(tl, M2, j, L::B, dx0);
-      ld16(tl, M2, j, L::B + 16, dx1);
-      ld16(tl, M2, j, L::C, t0);
-      ld16(tl, M2, j, L::C + 16, t1);
-      MZB(6, AUX + G2_AUX_X_AUX, filter, [&](int i) {
-        u64 v = econv_c0(l0, l1, l0, l1, i);
-        return i < 16 ? gl_sub(v, gl_add(gl_add(ax0[i < 16 ? i : 0], dx0[i < 16 ? i : 0]), t0[i < 16 ? i : 0])) : v;
-      });
-      MZB(7, AUX + G2_AUX_X_AUX + 80, filter, [&](int i) {
-        u64 v = econv_c1(l0, l1, l0, l1, i);
-        return i < 16 ? gl_sub(v, gl_add(gl_add(ax1[i < 16 ? i : 0], dx1[i < 16 ? i : 0]), t1[i < 16 ? i : 0])) : v;
-      });
+#pragma unroll 4
+      for (int i = 0; i < 16; i++) {
+        seed_w(sd0, 6, i, gl_neg(gl_add(gl_add(TL(L::A + i), TL(L::B + i)), TL(L::C + i))));
+        seed_w(sd1, 7, i, gl_neg(gl_add(gl_add(TL(L::A + 16 + i), TL(L::B + 16 + i)), TL(L::C + 16 + i))));
+      }
+      ld16(tl, M2, j, AUX + G2_AUX_LAMBDA, l0);
+      ld16(tl, M2, j, AUX + G2_AUX_LAMBDA + 16, l1);
+      MZB(6, AUX + G2_AUX_X_AUX, filter, [&](int i) { return econv_c0(l0, l1, l0, l1, i); }, &sd0);
+      MZB(7, AUX + G2_AUX_X_AUX + 80, filter, [&](int i) { return econv_c1(l0, l1, l0, l1, i); }, &sd1);
     } else {
       // lambda * (c.x - a.x) + c.y + a.y
-      ld16(tl, M2, j, L::C, dx0);
-      ld16(tl, M2, j, L::C + 16, dx1);
+#pragma unroll 4
+      for (int i = 0; i < 16; i++) {
+        seed_w(sd0, 8, i, gl_add(TL(L::C + 32 + i), TL(L::A + 32 + i)));
+        seed_w(sd1, 9, i, gl_add(TL(L::C + 48 + i), TL(L::A + 48 + i)));
+      }
+      ld16(tl, M2, j, AUX + G2_AUX_LAMBDA, l0);
+      ld16(tl, M2, j, AUX + G2_AUX_LAMBDA + 16, l1);
 #pragma unroll
       for (int i = 0; i < 16; i++) {
-        dx0[i] = gl_sub(dx0[i], ax0[i]);
-        dx1[i] = gl_sub(dx1[i], ax1[i]);
+        dx0[i] = gl_sub(TL(L::C + i), TL(L::A + i));
+        dx1[i] = gl_sub(TL(L::C + 16 + i), TL(L::A + 16 + i));
       }
-      ld16(tl, M2, j, L::C + 32, t0);
-      ld16(tl, M2, j, L::C + 48, t1);
-      ld16(tl, M2, j, L::A + 32, ax0);  // a.y
-      ld16(tl, M2, j, L::A + 48, ax1);
-      MZB(8, AUX + G2_AUX_Y_AUX, filter, [&](int i) {
-        u64 v = econv_c0(l0, l1, dx0, dx1, i);
-        return i < 16 ? gl_add(v, gl_add(t0[i < 16 ? i : 0], ax0[i < 16 ? i : 0])) : v;
-      });
-      MZB(9, AUX + G2_AUX_Y_AUX + 80, filter, [&](int i) {
-        u64 v = econv_c1(l0, l1, dx0, dx1, i);
-        return i < 16 ? gl_add(v, gl_add(t1[i < 16 ? i : 0], ax1[i < 16 ? i : 0])) : v;
-      });
+      MZB(8, AUX + G2_AUX_Y_AUX, filter, [&](int i) { return econv_c0(l0, l1, dx0, dx1, i); }, &sd0);
+      MZB(9, AUX + G2_AUX_Y_AUX + 80, filter, [&](int i) { return econv_c1(l0, l1, dx0, dx1, i); }, &sd1);
     }
   }
   store_part(A, part, j, tot0, tot1);

@@ -52,10 +52,23 @@ __device__ __forceinline__ u64 conv16(const u64* A, const u64* B, int i) {
 template <class InFn>
 __device__ __forceinline__ void mz_block(const u64* __restrict__ tl, size_t M2, size_t j, int auxcol, const u64* __restrict__ w0,
                                          const u64* __restrict__ w1, const u64* __restrict__ T0, const u64* __restrict__ T1,
-                                         u64 filter, InFn in, u64& tot0, u64& tot1) {
-  Acc2 pos, neg, q;
+                                         u64 filter, InFn in, u64& tot0, u64& tot1, const Acc2* seed = nullptr) {
+  // `seed`: the weighted sum of a part of the input polynomial that the caller accumulated beforehand (the block is linear
+  // in its input: terms that need other trace columns than the limb products are summed first, with no operand arrays live)
+  // the input polynomial first (its limb products need the most registers), reduced to two field elements before the
+  // witness columns of the block are summed
+  u64 n0, n1;
+  {
+    Acc2 neg;
+    if (seed) neg = *seed;
+    else acc2_init(neg);
+#pragma unroll
+    for (int i = 0; i < 31; i++) acc2_mad(neg, in(i), w0[1 + i], w1[1 + i]);
+    n0 = acc_red(neg.a0);
+    n1 = acc_red(neg.a1);
+  }
+  Acc2 pos, q;
   acc2_init(pos);
-  acc2_init(neg);
   acc2_init(q);
   const u64 iqp = TL(auxcol + QMZ_IQP);
   acc2_mad(pos, gl_sub(gl_mul(iqp, iqp), iqp), w0[0], w1[0]);
@@ -67,12 +80,10 @@ __device__ __forceinline__ void mz_block(const u64* __restrict__ tl, size_t M2, 
     acc2_mad(pos, TL(auxcol + QMZ_LO + d), T0[17 + d], T1[17 + d]);
     acc2_mad(pos, TL(auxcol + QMZ_HI + d), T0[48 + d], T1[48 + d]);
   }
-#pragma unroll
-  for (int i = 0; i < 31; i++) acc2_mad(neg, in(i), w0[1 + i], w1[1 + i]);
   u64 s0 = gl_add(acc_red(pos.a0), gl_mul(qsign, acc_red(q.a0)));
   u64 s1 = gl_add(acc_red(pos.a1), gl_mul(qsign, acc_red(q.a1)));
-  s0 = gl_sub(gl_sub(s0, T0[79]), acc_red(neg.a0));
-  s1 = gl_sub(gl_sub(s1, T1[79]), acc_red(neg.a1));
+  s0 = gl_sub(gl_sub(s0, T0[79]), n0);
+  s1 = gl_sub(gl_sub(s1, T1[79]), n1);
   tot0 = gl_add(tot0, gl_mul(filter, s0));
   tot1 = gl_add(tot1, gl_mul(filter, s1));
 }

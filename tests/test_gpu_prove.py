@@ -92,13 +92,13 @@ def test_batch_matches_single(gpu_ctx):
 
 def test_argument_errors(gpu_ctx):
     """Error behaviour of the ABI (the reference panics; the library returns status codes):
-    empty batch -> INVALID_ARG (-1); more than 8192 instances in ONE proof (2^23 rows) -> UNSUPPORTED (-5);
+    empty batch -> INVALID_ARG (-1); more than 16384 instances in ONE proof (2^24 rows) -> UNSUPPORTED (-5);
     min_rows below 2^16 -> UNSUPPORTED, where the reference panics with an out-of-bounds index in generate_range_checks."""
     import plonky2_bn254_amd as pk
     s, x, o = synth.g1_inputs(2, seed=1)
     with pytest.raises(RuntimeError, match="-1"):
         gpu_ctx.prove_g1(s[:0], x[:0], o[:0])
-    big = [np.repeat(a[:1], 8193, axis=0) for a in (s, x, o)]
+    big = [np.repeat(a[:1], 16385, axis=0) for a in (s, x, o)]
     with pytest.raises(RuntimeError, match="-5"):
         gpu_ctx.prove_g1(*big)
     p = pk.default_params()
