@@ -28,7 +28,7 @@ __global__ __launch_bounds__(256) void k_quotient_g1_sched(QArgs A) {
 }
 
 template <int part>
-__global__ __launch_bounds__(256, 3) void k_quotient_g1_add(QArgs A) {
+__global__ __launch_bounds__(256, 2) void k_quotient_g1_add(QArgs A) {
   const unsigned log_n = A.log_n;
   const size_t N = (size_t)1 << log_n, M2 = 2 * N;
   const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -51,8 +51,8 @@ __global__ __launch_bounds__(256, 3) void k_quotient_g1_add(QArgs A) {
     for (int i = 0; i < 16; i++) u16[i] = gl_sub(u16[i], ax[i]);  // delta_x
     ld16(tl, M2, j, AUX + G1_AUX_IS_X_EQ_AUX, t16);               // inv limbs
     const u64 c0 = gl_sub(is_x_eq, 1);
-    mz_block(tl, M2, j, AUX + G1_AUX_IS_X_EQ_AUX + 16, W0 + G1_MZ_E0[0], W1 + G1_MZ_E0[0], A.mzt + 0 * 160, A.mzt + 0 * 160 + 80,
-             filter, [&](int i) { u64 v = conv16(u16, t16, i); return i == 0 ? gl_add(v, c0) : v; }, tot0, tot1);
+    mz_block<true>(tl, M2, j, AUX + G1_AUX_IS_X_EQ_AUX + 16, W0 + G1_MZ_E0[0], W1 + G1_MZ_E0[0], A.mzt + 0 * 160, A.mzt + 0 * 160 + 80,
+             filter, [&](int i) __attribute__((always_inline)) { u64 v = conv16<true>(u16, t16, i); return i == 0 ? gl_add(v, c0) : v; }, tot0, tot1);
     e = 33;
     Acc2 g;
     acc2_init(g);
@@ -71,10 +71,10 @@ __global__ __launch_bounds__(256, 3) void k_quotient_g1_add(QArgs A) {
     for (int i = 0; i < 16; i++) u16[i] = gl_sub(u16[i], ax[i]);  // delta_x
     ld16(tl, M2, j, G1_COL_B + 16, t16);                          // b.y
     ld16(tl, M2, j, G1_COL_A + 16, ax);                           // a.y (a.x no longer needed)
-    mz_block(tl, M2, j, AUX + G1_AUX_LAMBDA_AUX, W0 + G1_MZ_E0[1], W1 + G1_MZ_E0[1], A.mzt + 1 * 160, A.mzt + 1 * 160 + 80,
+    mz_block<true>(tl, M2, j, AUX + G1_AUX_LAMBDA_AUX, W0 + G1_MZ_E0[1], W1 + G1_MZ_E0[1], A.mzt + 1 * 160, A.mzt + 1 * 160 + 80,
              gl_sub(filter, is_x_eq_filter),
-             [&](int i) {
-               u64 v = conv16(lam, u16, i);
+             [&](int i) __attribute__((always_inline)) {
+               u64 v = conv16<true>(lam, u16, i);
                return i < 16 ? gl_sub(v, gl_sub(t16[i < 16 ? i : 0], ax[i < 16 ? i : 0])) : v;
              },
              tot0, tot1);
@@ -82,10 +82,10 @@ __global__ __launch_bounds__(256, 3) void k_quotient_g1_add(QArgs A) {
     // block 2: 2*lambda*a.y - 3*a.x^2 under is_x_eq_filter, then a.y == b.y (e = 116..131)
     ld16(tl, M2, j, AUX + G1_AUX_LAMBDA, lam);
     ld16(tl, M2, j, G1_COL_A + 16, u16);  // a.y
-    mz_block(tl, M2, j, AUX + G1_AUX_LAMBDA_AUX, W0 + G1_MZ_E0[2], W1 + G1_MZ_E0[2], A.mzt + 2 * 160, A.mzt + 2 * 160 + 80,
+    mz_block<true>(tl, M2, j, AUX + G1_AUX_LAMBDA_AUX, W0 + G1_MZ_E0[2], W1 + G1_MZ_E0[2], A.mzt + 2 * 160, A.mzt + 2 * 160 + 80,
              is_x_eq_filter,
-             [&](int i) {
-               u64 ly = conv16(lam, u16, i), xx = conv16(ax, ax, i);
+             [&](int i) __attribute__((always_inline)) {
+               u64 ly = conv16<true>(lam, u16, i), xx = conv16<true>(ax, ax, i);
                return gl_sub(gl_dbl(ly), gl_add(gl_dbl(xx), xx));
              },
              tot0, tot1);
@@ -102,9 +102,9 @@ __global__ __launch_bounds__(256, 3) void k_quotient_g1_add(QArgs A) {
     ld16(tl, M2, j, AUX + G1_AUX_LAMBDA, lam);
     ld16(tl, M2, j, G1_COL_B, t16);
     ld16(tl, M2, j, G1_COL_C, u16);
-    mz_block(tl, M2, j, AUX + G1_AUX_X_AUX, W0 + G1_MZ_E0[3], W1 + G1_MZ_E0[3], A.mzt + 3 * 160, A.mzt + 3 * 160 + 80, filter,
-             [&](int i) {
-               u64 v = conv16(lam, lam, i);
+    mz_block<true>(tl, M2, j, AUX + G1_AUX_X_AUX, W0 + G1_MZ_E0[3], W1 + G1_MZ_E0[3], A.mzt + 3 * 160, A.mzt + 3 * 160 + 80, filter,
+             [&](int i) __attribute__((always_inline)) {
+               u64 v = conv16<true>(lam, lam, i);
                return i < 16 ? gl_sub(v, gl_add(gl_add(ax[i < 16 ? i : 0], t16[i < 16 ? i : 0]), u16[i < 16 ? i : 0])) : v;
              },
              tot0, tot1);
@@ -116,9 +116,9 @@ __global__ __launch_bounds__(256, 3) void k_quotient_g1_add(QArgs A) {
     for (int i = 0; i < 16; i++) u16[i] = gl_sub(u16[i], ax[i]);  // c.x - a.x
     ld16(tl, M2, j, G1_COL_C + 16, t16);                          // c.y
     ld16(tl, M2, j, G1_COL_A + 16, ax);                           // a.y
-    mz_block(tl, M2, j, AUX + G1_AUX_Y_AUX, W0 + G1_MZ_E0[4], W1 + G1_MZ_E0[4], A.mzt + 4 * 160, A.mzt + 4 * 160 + 80, filter,
-             [&](int i) {
-               u64 v = conv16(lam, u16, i);
+    mz_block<true>(tl, M2, j, AUX + G1_AUX_Y_AUX, W0 + G1_MZ_E0[4], W1 + G1_MZ_E0[4], A.mzt + 4 * 160, A.mzt + 4 * 160 + 80, filter,
+             [&](int i) __attribute__((always_inline)) {
+               u64 v = conv16<true>(lam, u16, i);
                return i < 16 ? gl_add(v, gl_add(t16[i < 16 ? i : 0], ax[i < 16 ? i : 0])) : v;
              },
              tot0, tot1);

@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256, 2) void k_quotient_g2_add(QArgs A) {
     {
       ld16(tl, M2, j, AUX + G2_AUX_C0_AUX, t0);  // inv of delta_x.c0
       const u64 c0 = gl_sub(z0, 1);
-      MZB(0, AUX + G2_AUX_C0_AUX + 16, filter, [&](int i) { u64 v = conv16(dx0, t0, i); return i == 0 ? gl_add(v, c0) : v; });
+      MZB(0, AUX + G2_AUX_C0_AUX + 16, filter, [&](int i) __attribute__((always_inline)) { u64 v = conv16(dx0, t0, i); return i == 0 ? gl_add(v, c0) : v; });
       e = 34;
       Acc2 g;
       acc2_init(g);
@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256, 2) void k_quotient_g2_add(QArgs A) {
     {
       ld16(tl, M2, j, AUX + G2_AUX_C1_AUX, t0);  // inv of delta_x.c1
       const u64 c0 = gl_sub(z1, 1);
-      MZB(1, AUX + G2_AUX_C1_AUX + 16, filter, [&](int i) { u64 v = conv16(dx1, t0, i); return i == 0 ? gl_add(v, c0) : v; });
+      MZB(1, AUX + G2_AUX_C1_AUX + 16, filter, [&](int i) __attribute__((always_inline)) { u64 v = conv16(dx1, t0, i); return i == 0 ? gl_add(v, c0) : v; });
       e = 83;
       Acc2 g;
       acc2_init(g);
@@ -110,8 +110,8 @@ __global__ __launch_bounds__(256, 2) void k_quotient_g2_add(QArgs A) {
         dx1[i] = gl_sub(TL(L::B + 16 + i), TL(L::A + 16 + i));
       }
       const u64 f_ne = gl_sub(filter, is_x_eq_filter);
-      MZB(2, AUX + G2_AUX_LAMBDA_AUX, f_ne, [&](int i) { return econv_c0(l0, l1, dx0, dx1, i); }, &sd0);
-      MZB(3, AUX + G2_AUX_LAMBDA_AUX + 80, f_ne, [&](int i) { return econv_c1(l0, l1, dx0, dx1, i); }, &sd1);
+      MZB(2, AUX + G2_AUX_LAMBDA_AUX, f_ne, [&](int i) __attribute__((always_inline)) { return econv_c0(l0, l1, dx0, dx1, i); }, &sd0);
+      MZB(3, AUX + G2_AUX_LAMBDA_AUX + 80, f_ne, [&](int i) __attribute__((always_inline)) { return econv_c1(l0, l1, dx0, dx1, i); }, &sd1);
     } else if constexpr (part == 2) {
       // 2 * lambda * a.y - 3 * a.x^2 under is_x_eq_filter, then a.y == b.y
       ld16(tl, M2, j, L::A, dx0);  // a.x: its squares go into the seeds, then the arrays are reused for a.y
@@ -126,8 +126,8 @@ __global__ __launch_bounds__(256, 2) void k_quotient_g2_add(QArgs A) {
       ld16(tl, M2, j, AUX + G2_AUX_LAMBDA + 16, l1);
       ld16(tl, M2, j, L::A + 32, dx0);  // a.y
       ld16(tl, M2, j, L::A + 48, dx1);
-      MZB(4, AUX + G2_AUX_LAMBDA_AUX, is_x_eq_filter, [&](int i) { return gl_dbl(econv_c0(l0, l1, dx0, dx1, i)); }, &sd0);
-      MZB(5, AUX + G2_AUX_LAMBDA_AUX + 80, is_x_eq_filter, [&](int i) { return gl_dbl(econv_c1(l0, l1, dx0, dx1, i)); }, &sd1);
+      MZB(4, AUX + G2_AUX_LAMBDA_AUX, is_x_eq_filter, [&](int i) __attribute__((always_inline)) { return gl_dbl(econv_c0(l0, l1, dx0, dx1, i)); }, &sd0);
+      MZB(5, AUX + G2_AUX_LAMBDA_AUX + 80, is_x_eq_filter, [&](int i) __attribute__((always_inline)) { return gl_dbl(econv_c1(l0, l1, dx0, dx1, i)); }, &sd1);
       e = 232;
       Acc2 g;
       acc2_init(g);
@@ -146,8 +146,8 @@ __global__ __launch_bounds__(256, 2) void k_quotient_g2_add(QArgs A) {
       }
       ld16(tl, M2, j, AUX + G2_AUX_LAMBDA, l0);
       ld16(tl, M2, j, AUX + G2_AUX_LAMBDA + 16, l1);
-      MZB(6, AUX + G2_AUX_X_AUX, filter, [&](int i) { return econv_c0(l0, l1, l0, l1, i); }, &sd0);
-      MZB(7, AUX + G2_AUX_X_AUX + 80, filter, [&](int i) { return econv_c1(l0, l1, l0, l1, i); }, &sd1);
+      MZB(6, AUX + G2_AUX_X_AUX, filter, [&](int i) __attribute__((always_inline)) { return econv_c0(l0, l1, l0, l1, i); }, &sd0);
+      MZB(7, AUX + G2_AUX_X_AUX + 80, filter, [&](int i) __attribute__((always_inline)) { return econv_c1(l0, l1, l0, l1, i); }, &sd1);
     } else {
       // lambda * (c.x - a.x) + c.y + a.y
 #pragma unroll 4
@@ -162,8 +162,8 @@ __global__ __launch_bounds__(256, 2) void k_quotient_g2_add(QArgs A) {
         dx0[i] = gl_sub(TL(L::C + i), TL(L::A + i));
         dx1[i] = gl_sub(TL(L::C + 16 + i), TL(L::A + 16 + i));
       }
-      MZB(8, AUX + G2_AUX_Y_AUX, filter, [&](int i) { return econv_c0(l0, l1, dx0, dx1, i); }, &sd0);
-      MZB(9, AUX + G2_AUX_Y_AUX + 80, filter, [&](int i) { return econv_c1(l0, l1, dx0, dx1, i); }, &sd1);
+      MZB(8, AUX + G2_AUX_Y_AUX, filter, [&](int i) __attribute__((always_inline)) { return econv_c0(l0, l1, dx0, dx1, i); }, &sd0);
+      MZB(9, AUX + G2_AUX_Y_AUX + 80, filter, [&](int i) __attribute__((always_inline)) { return econv_c1(l0, l1, dx0, dx1, i); }, &sd1);
     }
   }
   store_part(A, part, j, tot0, tot1);
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256) void k_quotient_fq_mul(QArgs A) {
   ld16(tl, M2, j, L::C, c);
   // eval_fq_mul: a*b - c
   mz_block(tl, M2, j, L::AUX, W0 + FQ_MZ_E0[0], W1 + FQ_MZ_E0[0], A.mzt, A.mzt + 80, filter,
-           [&](int i) {
+           [&](int i) __attribute__((always_inline)) {
              u64 v = conv16(a, b, i);
              return i < 16 ? gl_sub(v, c[i < 16 ? i : 0]) : v;
            },

@@ -37,19 +37,31 @@ __device__ __forceinline__ void ld16(const u64* __restrict__ tl, size_t M2, size
   for (int i = 0; i < 16; i++) v[i] = tl[(size_t)(col + i) * M2 + j];
 }
 // coefficient i of the limb product A*B (pol_mul_wide), reduced
+// FULL: unrolled completely, operands in registers (G1: three or four operand arrays, no scratch at two waves per SIMD);
+// otherwise the compiler keeps the loops rolled and the operand arrays in private memory with uniform indices (G2, whose
+// eight Fq2 operand arrays do not fit: unrolled completely it spills 0.5-2.4 KB per lane)
+template <bool FULL = false>
 __device__ __forceinline__ u64 conv16(const u64* A, const u64* B, int i) {
   Acc a;
   acc_init(a);
+  if constexpr (FULL) {
+#pragma clang loop unroll(full)
+    for (int s = 0; s < 16; s++) {
+      int t = i - s;
+      if (t >= 0 && t < 16) acc_mad(a, A[s], B[t]);
+    }
+  } else {
 #pragma unroll
-  for (int s = 0; s < 16; s++) {
-    int t = i - s;
-    if (t >= 0 && t < 16) acc_mad(a, A[s], B[t]);
+    for (int s = 0; s < 16; s++) {
+      int t = i - s;
+      if (t >= 0 && t < 16) acc_mad(a, A[s], B[t]);
+    }
   }
   return acc_red(a);
 }
 
 // One eval_modulus_zero block.  `in(i)` returns coefficient i (0..30) of the input polynomial.
-template <class InFn>
+template <bool FULL = false, class InFn>
 __device__ __forceinline__ void mz_block(const u64* __restrict__ tl, size_t M2, size_t j, int auxcol, const u64* __restrict__ w0,
                                          const u64* __restrict__ w1, const u64* __restrict__ T0, const u64* __restrict__ T1,
                                          u64 filter, InFn in, u64& tot0, u64& tot1, const Acc2* seed = nullptr) {
@@ -62,8 +74,13 @@ __device__ __forceinline__ void mz_block(const u64* __restrict__ tl, size_t M2, 
     Acc2 neg;
     if (seed) neg = *seed;
     else acc2_init(neg);
+    if constexpr (FULL) {
+#pragma clang loop unroll(full)
+      for (int i = 0; i < 31; i++) acc2_mad(neg, in(i), w0[1 + i], w1[1 + i]);
+    } else {
 #pragma unroll
-    for (int i = 0; i < 31; i++) acc2_mad(neg, in(i), w0[1 + i], w1[1 + i]);
+      for (int i = 0; i < 31; i++) acc2_mad(neg, in(i), w0[1 + i], w1[1 + i]);
+    }
     n0 = acc_red(neg.a0);
     n1 = acc_red(neg.a1);
   }
