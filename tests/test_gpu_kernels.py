@@ -42,6 +42,31 @@ def test_commit_values_matches_oracle(gpu_ctx, oracle, ncols):
     assert np.array_equal(cap, cap_ref)
 
 
+def test_commit_values_structured_columns(gpu_ctx, oracle):
+    """from_values on columns made of boundary values (0, 1, p-1, 2^32 +- 1, 2^64 - 2^32, ...) in random mixtures, impulses,
+    alternating and constant columns: the carry / borrow / wrap paths of the hand-written butterflies, twiddles and products
+    inside the real kernels, every coefficient and every LDE value against the oracle."""
+    rng = np.random.default_rng(2024)
+    edge = np.array([0, 1, 2, P - 1, P - 2, 2**32 - 1, 2**32, 2**32 + 1, P - 2**32, 2**63, 2**48, 0xFFFFFFFE00000001,
+                     0xFFFFFFFEFFFFFFFF, 0x00000001FFFFFFFF, 0xFFFF0000FFFF0001], dtype=np.uint64)
+    cols = []
+    for k in range(6):
+        cols.append(edge[rng.integers(0, edge.size, size=65536)])           # dense mixtures of boundary values
+    imp = np.zeros(65536, np.uint64); imp[0] = 1; cols.append(imp)            # impulse: flat spectrum
+    imp = np.zeros(65536, np.uint64); imp[65535] = np.uint64(P - 1); cols.append(imp)
+    alt = np.zeros(65536, np.uint64); alt[::2] = np.uint64(P - 1); cols.append(alt)
+    cols.append(np.full(65536, np.uint64(2**32 - 1)))
+    sparse = np.zeros(65536, np.uint64); sparse[rng.integers(0, 65536, size=40)] = edge[rng.integers(0, edge.size, size=40)]
+    cols.append(sparse)
+    mix = rand_field(rng, 65536); mix[rng.integers(0, 65536, size=20000)] = np.uint64(P - 1); cols.append(mix)
+    vals = np.stack(cols)
+    c_ref, l_ref, cap_ref = oracle_lib.commit_values(oracle, vals)
+    c, l, cap = gpu_ctx.commit_values(vals)
+    assert np.array_equal(c, c_ref)
+    assert np.array_equal(l, l_ref)
+    assert np.array_equal(cap, cap_ref)
+
+
 def test_ntt_linearity_full_width(gpu_ctx):
     """Size-independent property at the bench's full width: LDE(a+b) = LDE(a)+LDE(b) on 64 columns."""
     rng = np.random.default_rng(7)
