@@ -78,7 +78,7 @@ def step_inputs(pool, step: int, rank: int):
 
 def caps_of(proofs) -> np.ndarray:
     """[n_proofs, 192] the three Merkle caps (trace, aux, quotient) of every proof."""
-    return np.stack([p.words[:192] for p in proofs]).astype(np.uint64)
+    return np.stack([p.caps() for p in proofs]).astype(np.uint64)
 
 
 def gather_caps(local_caps: np.ndarray, dist, device):

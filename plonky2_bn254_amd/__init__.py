@@ -8,6 +8,6 @@ include/bn254_stark.h).  This package is the thin host-side mirror used by tests
 import os as _os
 
 # one hardware queue per proof in flight (see csrc/capi.hip); must be in the environment before the HIP runtime starts
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 from .lib import Context, Proof, load_library, LibraryMissing, VerifyError, default_params, prove_batch_multi, verify_host  # noqa: F401

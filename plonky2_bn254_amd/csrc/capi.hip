@@ -35,7 +35,7 @@ void bn254s_params_default(bn254s_params* p) {
 // Six proofs in flight use six HIP streams; the runtime's default of four hardware queues would make pairs of streams share
 // one queue and serialise behind each other's long kernels (measured: 36 -> 40 proofs/s).  The variable is read when the HIP
 // runtime initialises, so it is set when the library is loaded and never overrides a value the user chose.
-__attribute__((constructor)) static void bn254s_runtime_defaults() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+__attribute__((constructor)) static void bn254s_runtime_defaults() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
 
 
 int bn254s_ctx_create(int device_id, bn254s_ctx** out) {

@@ -739,7 +739,7 @@ int bn254s_prove_batch(bn254s_ctx* c, int kind, const bn254s_params* params, con
   const size_t PW = point_words(kind);
   for (size_t i = 0; i < n_proofs; i++) proofs_out[i] = nullptr;
   HIP_TRY(c, hipSetDevice(c->device));
-  size_t n_slots = 8;  // proofs in flight (one stream, host thread and workspace each; GPU_MAX_HW_QUEUES = 8)
+  size_t n_slots = 8;  // proofs in flight (one stream, host thread and workspace each; GPU_MAX_HW_QUEUES = 16 gives every stream its own hardware queue)
   if (const char* e = getenv("BN254S_SLOTS")) n_slots = std::max(1, atoi(e));
   n_slots = std::min(n_slots, n_proofs);
   for (size_t s = 0; s < n_slots; s++)

@@ -98,17 +98,43 @@ def _ptr(a: Optional[np.ndarray]):
 class Proof:
     """Owns a bn254s_proof*; `words` is the canonical u64 layout documented in bn254_stark.h."""
 
+    _stage_names = None
+
     def __init__(self, lib, handle):
         self._lib, self._h = lib, handle
-        data, n = U64P(), C.c_size_t()
-        lib.bn254s_proof_words(handle, C.byref(data), C.byref(n))
-        self.words = np.ctypeslib.as_array(data, shape=(n.value,)).copy()
-        lib.bn254s_proof_outputs(handle, C.byref(data), C.byref(n))
-        self.outputs = np.ctypeslib.as_array(data, shape=(n.value,)).copy() if n.value else np.zeros(0, np.uint64)
+        self._words = self._outputs = None
         self.degree_bits = lib.bn254s_proof_degree_bits(handle)
         ms, k = C.POINTER(C.c_float)(), C.c_size_t()
         lib.bn254s_proof_stage_ms(handle, C.byref(ms), C.byref(k))
-        self.stage_ms = {lib.bn254s_stage_name(i).decode(): float(ms[i]) for i in range(k.value)}
+        if Proof._stage_names is None or len(Proof._stage_names) != k.value:
+            Proof._stage_names = [lib.bn254s_stage_name(i).decode() for i in range(k.value)]
+        self.stage_ms = dict(zip(Proof._stage_names, ms[:k.value]))
+
+    # the 1.1 MB of proof words are copied out of the library's buffer on first use (a throughput loop that only needs the caps
+    # and the stage times does not pay for eight copies per step)
+    @property
+    def words(self) -> np.ndarray:
+        if self._words is None:
+            data, n = U64P(), C.c_size_t()
+            self._lib.bn254s_proof_words(self._h, C.byref(data), C.byref(n))
+            self._words = np.ctypeslib.as_array(data, shape=(n.value,)).copy()
+        return self._words
+
+    @property
+    def outputs(self) -> np.ndarray:
+        if self._outputs is None:
+            data, n = U64P(), C.c_size_t()
+            self._lib.bn254s_proof_outputs(self._h, C.byref(data), C.byref(n))
+            self._outputs = np.ctypeslib.as_array(data, shape=(n.value,)).copy() if n.value else np.zeros(0, np.uint64)
+        return self._outputs
+
+    def caps(self) -> np.ndarray:
+        """The three Merkle caps (trace, auxiliary, quotient): the first 192 words of the proof."""
+        if self._words is not None:
+            return self._words[:192].copy()
+        data, n = U64P(), C.c_size_t()
+        self._lib.bn254s_proof_words(self._h, C.byref(data), C.byref(n))
+        return np.ctypeslib.as_array(data, shape=(192,)).copy()
 
     SECTIONS = ("trace_cap", "auxiliary_polys_cap", "quotient_polys_cap", "local_values", "next_values", "auxiliary_polys",
                 "auxiliary_polys_next", "ctl_zs_first", "quotient_polys", "commit_phase_merkle_caps", "query_round_proofs",
