@@ -47,6 +47,7 @@ int bn254s_ctx_create(int device_id, bn254s_ctx** out) {
   bn254s_ctx* c = new bn254s_ctx();
   c->device = device_id;
   if (const char* e = getenv("BN254S_BIG_CAP")) c->big_cap = std::max(1, atoi(e));
+  if (const char* e = getenv("BN254S_SCHED_FIFO")) c->big_fifo = atoi(e) != 0;
   c->big_cost[BIG_NTT] = c->big_cap;
   const char* cost_env[3] = {"BN254S_BIG_COST_NTT", "BN254S_BIG_COST_EXCL", "BN254S_BIG_COST_HASH"};
   for (int k = 0; k < 3; k++) {

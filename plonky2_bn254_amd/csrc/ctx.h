@@ -66,16 +66,31 @@ struct bn254s_ctx : BufPool {
   // (doubling chain, upper Merkle levels, scans, PoW, FRI folds) run outside it and overlap freely.
   std::mutex big_mu;
   std::condition_variable big_cv;
-  // Weighted semaphore over the GPU-filling sections of all proofs in flight.  Classes (cost out of big_cap = 6):
-  //   BIG_NTT  (6): the NTT/LDE stage runs alone - it is the stage the roofline figure is quoted on;
+  // Weighted semaphore over the GPU-filling sections of all proofs in flight, admission in arrival order.  Classes (cost out
+  // of big_cap = 9):
+  //   BIG_NTT  (9): the NTT/LDE stage runs alone - it is the stage the roofline figure is quoted on;
   //   BIG_EXCL (3): quotient, auxiliary columns, range-check histogram, openings, FRI combine;
-  //   BIG_HASH (3): Poseidon leaf hashing - one 2^17-leaf launch puts two waves on a SIMD; two such sections run together
-  //                 (round 2 sweep with the hand-scheduled hash, tools/gpu_locksweep.sh: 70.1 proofs/s against 68.2 for the
-  //                 round-1 costs 3 / 2 / 1 out of 3 with six slots; letting the NTT stage share the GPU gives 71.2).
-  // BN254S_BIG_CAP / BN254S_BIG_COST_NTT / BN254S_BIG_COST_EXCL / BN254S_BIG_COST_HASH override the costs (tuning only).
-  int big_cap = 6, big_cost[3] = {6, 3, 3}, big_used = 0;
+  //   BIG_HASH (3): Poseidon leaf hashing (one 2^17-leaf launch puts two waves on a SIMD);
+  // so three of the cost-3 sections share the GPU.  Arrival order matters: without it a waiting NTT stage (which needs the whole
+  // capacity) was overtaken by later cost-3 sections - at the start of a call by the range-check histograms of all the other
+  // proofs - and the first wide arithmetic of a step started milliseconds late.  Repeating one batch (tools/step_overheads.py):
+  // 74.4-75.1 -> 77.4-77.9 proofs/s for the order alone, 78.9-79.6 with three concurrent sections; bench.py, whose steps prove
+  // fresh inputs and end on the slowest proof-of-work search of eight, measures no difference (76 either way).
+  // BN254S_BIG_CAP / BN254S_BIG_COST_NTT / BN254S_BIG_COST_EXCL / BN254S_BIG_COST_HASH / BN254S_SCHED_FIFO override (tuning only).
+  int big_cap = 9, big_cost[3] = {9, 3, 3}, big_used = 0;
+  bool big_fifo = false;
+  unsigned long big_ticket = 0, big_serving = 0;
   void big_lock(int cls) {
     std::unique_lock<std::mutex> lk(big_mu);
+    if (big_fifo) {
+      const unsigned long my = big_ticket++;
+      big_cv.wait(lk, [&] { return big_serving == my && big_used + big_cost[cls] <= big_cap; });
+      big_serving++;
+      big_used += big_cost[cls];
+      lk.unlock();
+      big_cv.notify_all();  // the next ticket may fit beside this one
+      return;
+    }
     big_cv.wait(lk, [&] { return big_used + big_cost[cls] <= big_cap; });
     big_used += big_cost[cls];
   }
