@@ -2,12 +2,14 @@
 //
 // The compiler's code for a canonical butterfly (a + b, (a - b) 2^S) is 6 + 6 + 18 vector instructions plus hazard
 // s_nops (it re-derives the borrow with a 64-bit compare, materialises 64-bit selects and reduces a shifted value through
-// the general 128-bit reduction).  The sequences below are the ones counted in profiles/r02_ntt_isa_budget.md:
+// the general 128-bit reduction).  The blocks below are inline asm whose operands the compiler allocates and which it
+// schedules as units; they are the sequences counted in profiles/r02_ntt_isa_budget.md:
 //   sum        5 VALU + 1 SALU   64-bit add, two 64-bit compares, one select, one multiply-add (s + (2^32-1) if needed)
 //   difference 5 VALU            two borrow chains (a - b, then - (2^32-1) if it borrowed)
 //   x 2^S, S <= 32         6 VALU + 1 SALU   (x << S) + (x >> (64-S)) (2^32-1) as ONE multiply-add with carry-out
 //   x 2^-K, K <= 32        9 VALU + 1 SALU   Montgomery-style: (x + m) >> K + m 2^(32-K) (2^32-1), m = -x mod 2^K
 //   x 2^(32+S)            11 VALU + 2 SALU   x 2^S, then y0 2^32 + y1 (2^32-1)
+//   a b                   19 VALU + 1 SALU   four multiply-adds chained through 64-bit shifts, no register moves
 // Every function takes canonical operands (< p) and returns canonical results; all of them are exact for every input
 // (tests/test_gpu_kernels.py::test_field_asm_edge_cases drives them with boundary values against Python integers).
 //

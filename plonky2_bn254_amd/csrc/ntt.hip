@@ -14,20 +14,14 @@
 //                         either in natural order or in bit-reversed (Merkle-leaf) order.
 // The 2N-point coset LDE is computed as two N-point coset NTTs (cosets g and g*w_2N); in bit-reversed
 // order they are the lower and upper half of the output, so no separate zero-padded 2N transform and
-// no bit-reversal pass exist.  Global accesses are 128-byte segments (16 lanes x 8 B) or 16-byte
-// vectors; twiddle / coset tables have the same access pattern as the data and stay L2-resident.
+// no bit-reversal pass exist.  Global accesses are 128-byte segments (16 lanes x 8 B), or 1 KB per store
+// instruction where the output is staged through LDS; twiddle / coset tables have the same access pattern
+// as the data and stay L2-resident.  The arithmetic is the hand-written code of gl_asm.h.
 #include "gl_dev.h"
 #include "gl_asm.h"
 #include "ntt.h"
 
 // ---- radix-16 DFT in registers --------------------------------------------------------------------------
-// x*w16^e with w16 = 2^12 (forward) or 2^-12 (inverse); e in [0,8).
-template <bool INV, int E>
-__device__ __forceinline__ u64 mul_w16(u64 x) {
-  if constexpr (E == 0) return x;
-  else if constexpr (!INV) return gl_mul_2exp<12 * E>(x);
-  else return gl_mul_2exp<192 - 12 * E>(x);
-}
 template <bool INV, int SPAN, int G, int J>
 __device__ __forceinline__ void bfly16(u64* x) {
   constexpr int E = J * (8 / SPAN);
