@@ -88,7 +88,8 @@ const char* bn254s_last_error(const bn254s_ctx* ctx);
 /* Prove n G1 scalar multiplications s_i * x_i + offset_i in ONE STARK (timestamps 0..n-1), like
  * G1ScalarMulStark::generate_trace + prove (scalar_mul_stark.rs:55-69, common/prover.rs:18-72).
  * rows = max(2^min_rows_log2, 512 n) rounded up to a power of two; 2^16 .. 2^23 rows (n <= 16384) are supported
- * (a G1 proof of 2^22 rows keeps about 200 GB resident, one of 2^23 rows about 245 GB: its workspace is laid out to fit),
+ * (a G1 proof of 2^22 rows keeps about 200 GB resident, one of 2^23 rows about 245 GB: its workspace is laid out to fit;
+ * a G2 proof of 2^23 rows would need about 370 GB and returns BN254S_E_OOM on a 288 GB device, 2^22 rows fit),
  * i.e. one proof can cover all calls of a circuit exactly as Bn254Hook::constrain batches them (hook.rs:63-71). */
 int bn254s_prove_g1(bn254s_ctx* ctx, const bn254s_params* params, const uint64_t* scalars /* n x 4 */,
                     const uint64_t* x /* n x 8 */, const uint64_t* offset /* n x 8 */, size_t n, bn254s_proof** out);
