@@ -186,6 +186,12 @@ static int prove_on_slot(bn254s_ctx* c, Slot& sl, int kind, const bn254s_params&
   const size_t R = (size_t)1 << log_r;
   const size_t M2 = 2 * N, NH = N >> log_s;  // NH: words of one half (= N without the extra level)
   const int NSPL = 1 << log_s;              // coefficient arrays hold NSPL halves per polynomial
+  // The compact workspace (NTT stage in column chunks, auxiliary commitment in place, auxiliary LDE in the memory of the dead
+  // trace values) is used whenever the plain layout would not fit: 2^23 rows, and G2 from 2^22 rows on (339 GB plain, 211 GB
+  // compact).  BN254S_FORCE_LOWMEM=1 selects it for any tall proof (tests).
+  const bool force_lowmem = getenv("BN254S_FORCE_LOWMEM") && atoi(getenv("BN254S_FORCE_LOWMEM"));
+  const double plain_bytes = 8.0 * (double)N * (4.0 * sh.W + 4.0 * sh.n_aux() + std::max(sh.W, sh.n_aux()));
+  const bool lowmem = log_s || (log_n > 16 && (force_lowmem || plain_bytes > 200e9));
   const int W = sh.W, A = sh.n_aux(), NQ = 4, CAPW = 64;
   const int K = sh.n_total_constraints();
   hipStream_t st = sl.st;
@@ -226,6 +232,11 @@ static int prove_on_slot(bn254s_ctx* c, Slot& sl, int kind, const bn254s_params&
         ntt_inverse_lde_tall(&c->ntt, TT, coef + (size_t)c0 * N, coef + (size_t)c0 * N, eo, ntmp, 2 * cn, st);
         ntt_split_forward(SP, eo, lde + (size_t)c0 * M2, M2, cn, st);
       }
+    } else if (log_r && lowmem) {
+      for (int c0 = 0; c0 < nc; c0 += CH) {
+        const int cn = std::min(CH, nc - c0);
+        ntt_inverse_lde_tall(&c->ntt, TT, vals + (size_t)c0 * N, coef + (size_t)c0 * N, lde + (size_t)c0 * M2, d_tmp_fwd, cn, st);
+      }
     } else if (log_r) {
       ntt_inverse_lde_tall(&c->ntt, TT, vals, coef, lde, d_tmp_fwd, nc, st);
     } else {
@@ -250,20 +261,24 @@ static int prove_on_slot(bn254s_ctx* c, Slot& sl, int kind, const bn254s_params&
 
   // ---- workspace ------------------------------------------------------------------------------------------
   const size_t in_words = n * (4 + 2 * (size_t)PW);
+  if (lowmem) {  // buffers of the plain layout left in the slot by an earlier, smaller proof would not fit beside this one
+    mem.drop("acoef");
+    mem.drop("alde");
+  }
   u64* d_in = mem.words("in", in_words + 16);
-  // split level: the trace values are dead once the auxiliary values exist, the auxiliary LDE takes their place
-  u64* d_tvals = mem.words("tvals", log_s ? std::max((size_t)W * N, (size_t)A * M2) : (size_t)W * N);
+  // compact workspace: the trace values are dead once the auxiliary values exist, the auxiliary LDE takes their place
+  u64* d_tvals = mem.words("tvals", lowmem ? std::max((size_t)W * N, (size_t)A * M2) : (size_t)W * N);
   u64* d_tcoef = mem.words("tcoef", (size_t)W * N);
   u64* d_hist = mem.words("hist", 65536 / 2);
   // [tmp | y0 | y1] for the fused commitment; one tmp for a tall one; [E,O LDEs | tmp] of one column chunk under the split level
-  u64* d_tmp = mem.words("tmp", log_s ? (size_t)3 * CH * N : (size_t)(log_r ? 1 : 3) * std::max(W, A) * N);
+  u64* d_tmp = mem.words("tmp", log_s ? (size_t)3 * CH * N : lowmem ? (size_t)CH * N : (size_t)(log_r ? 1 : 3) * std::max(W, A) * N);
   d_tmp_fwd = d_tmp;
   u64* d_tlde = mem.words("tlde", (size_t)W * M2);
   const size_t tree_words = merkle_tree_digests(log_m2, P.cap_height) * 4;
   u64* d_trees = mem.words("trees", 3 * tree_words);
   u64* d_avals = mem.words("avals", (size_t)A * N);
-  u64* d_acoef = log_s ? d_avals : mem.words("acoef", (size_t)A * N);         // split level: the commitment runs in place
-  u64* d_alde = log_s ? d_tvals : mem.words("alde", (size_t)A * M2);
+  u64* d_acoef = lowmem ? d_avals : mem.words("acoef", (size_t)A * N);         // compact workspace: the commitment runs in place
+  u64* d_alde = lowmem ? d_tvals : mem.words("alde", (size_t)A * M2);
   const size_t trace_scr = kind == KIND_G1 ? g1_trace_scratch_words(n) : kind == KIND_G2 ? g2_trace_scratch_words(n) : fq_trace_scratch_words(n);
   u64* d_scr = mem.words("scratch", std::max(trace_scr, aux_scratch_words(sh, N)));
   u64* d_q = mem.words("quot", (size_t)(3 * NQ) * N + (size_t)NQ * M2 + (size_t)QUOTIENT_MAX_PARTS * 2 * M2);  // qv, ab, qcoef, qlde, partials

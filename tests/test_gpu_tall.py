@@ -36,6 +36,21 @@ def test_split_level_2pow18_matches_oracle(gpu_ctx, oracle, monkeypatch):
     assert np.array_equal(pr.outputs.reshape(-1, 4), ref_out)
 
 
+def test_compact_workspace_2pow17_matches_oracle(gpu_ctx, oracle, monkeypatch):
+    """The compact workspace of the proofs that would not fit otherwise (G1 at 2^23 rows, G2 from 2^22 rows on: NTT stage in
+    column chunks, auxiliary commitment in place, auxiliary LDE in the memory of the trace values) forced at 2^17 rows."""
+    s, x, o = synth.g1_inputs(150, seed=34)
+    ref, ref_out, _, degree_bits = oracle_lib.prove(oracle, 0, s, x, o)
+    monkeypatch.setenv("BN254S_FORCE_LOWMEM", "1")
+    pr = gpu_ctx.prove_g1(s, x, o)
+    monkeypatch.delenv("BN254S_FORCE_LOWMEM")
+    assert degree_bits == 17 and pr.words.shape == ref.shape
+    bad = np.flatnonzero(pr.words != ref)
+    assert bad.size == 0, f"first differing words {bad[:5]} of {ref.size}"
+    pr2 = gpu_ctx.prove_g1(s, x, o)          # back to the plain layout in the same slot
+    assert np.array_equal(pr2.words, ref)
+
+
 def test_g1_tall_proof_2pow17(gpu_ctx, oracle):
     s, x, o = synth.g1_inputs(150, seed=32)         # 76800 rows -> N = 2^17
     ref, ref_out, _, degree_bits = oracle_lib.prove(oracle, 0, s, x, o)
