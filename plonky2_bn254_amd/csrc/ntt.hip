@@ -505,13 +505,31 @@ __global__ __launch_bounds__(256) void k_ntt_outer_fwd(const u64* __restrict__ z
     f = gl_mul(f, b);
   }
   dft_small<LOGR, false>(x);
-  u64* o = out + (size_t)blockIdx.y * out_stride + p * R;
+  // A lane owns R consecutive output words; stored from there a wave writes 64 pieces of 16 bytes R*8 bytes apart per
+  // instruction (the pattern that made pass 2 store-issue bound).  Staged through LDS in chunks of at most 16 words per lane,
+  // eight neighbouring lanes write one 128-byte line per instruction.
+  constexpr int CH = R < 16 ? R : 16;        // words per lane and round
+  constexpr int U = CH / 2;                  // 16-byte units per lane and round
+  constexpr int PITCH = U + 1;               // padded: conflict-free writes
+  __shared__ ulonglong2 stage[256 * PITCH];
+  const int t = threadIdx.x;
+  ulonglong2* o16 = reinterpret_cast<ulonglong2*>(out + (size_t)blockIdx.y * out_stride + (size_t)blockIdx.x * 256 * R);
 #pragma unroll
-  for (int q = 0; q < R; q += 2) {
-    ulonglong2 w2;
-    w2.x = x[q];
-    w2.y = x[q + 1];
-    *reinterpret_cast<ulonglong2*>(o + q) = w2;
+  for (int c0 = 0; c0 < R; c0 += CH) {
+    if (c0) __syncthreads();
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      ulonglong2 w2;
+      w2.x = x[c0 + 2 * u];
+      w2.y = x[c0 + 2 * u + 1];
+      stage[t * PITCH + u] = w2;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < U; it++) {
+      const int piece = it * 256 + t, owner = piece / U, part = piece % U;
+      o16[(size_t)owner * (R / 2) + c0 / 2 + part] = stage[owner * PITCH + part];
+    }
   }
 }
 
