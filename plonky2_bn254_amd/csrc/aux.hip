@@ -69,6 +69,7 @@ __global__ __launch_bounds__(256) void k_logup_terms(const u64* __restrict__ tra
 // mode 1: out[i] = sum_{j >= i} in[j] (inclusive suffix).
 __global__ __launch_bounds__(1024) void k_scan(const u64* __restrict__ in, size_t in_stride, u64* __restrict__ out,
                                                size_t out_stride, size_t N, int mode) {
+  LATENCY_KERNEL_PRIO();
   __shared__ u64 part[1024];
   const int t = threadIdx.x;
   const u64* src = in + (size_t)blockIdx.x * in_stride;

@@ -28,6 +28,7 @@ static constexpr int OPEN_Q = (int)(65536 / 256);
 // zq3[(pt*OPEN_Q + q)*8 ..] = 22-bit limbs of the two components of ((z_pt^R)^256)^q (3 + 3 u32, padded to 8),
 // zt[(pt*256 + t)*2 ..] = (z_pt^R)^t
 __global__ __launch_bounds__(256) void k_opening_tables(gl2 z0r, gl2 z1r, u64* __restrict__ zq, u64* __restrict__ zt) {
+  LATENCY_KERNEL_PRIO();
   const int t = threadIdx.x;
   u32* zq3 = reinterpret_cast<u32*>(zq);
   for (int pt = 0; pt < 2; pt++) {
@@ -206,6 +207,7 @@ __device__ __forceinline__ constexpr int fbr4(int x) { return ((x & 1) << 3) | (
 
 __global__ __launch_bounds__(256) void k_fri_fold(const u64* __restrict__ in, u64* __restrict__ out, unsigned log_m, u64 shift,
                                                   gl2 beta, u64 inv16) {
+  LATENCY_KERNEL_PRIO();
   const size_t Mo = (size_t)1 << (log_m - 4);
   const size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= Mo) return;
@@ -248,6 +250,7 @@ struct PowArgs {
   unsigned long long* result;  // min over valid candidates, initialised to ~0
 };
 __global__ __launch_bounds__(256) void k_pow(PowArgs A) {
+  LATENCY_KERNEL_PRIO();
   u64 cand = A.base + (u64)blockIdx.x * blockDim.x + threadIdx.x;
   u64 s[12];
 #pragma unroll
@@ -275,6 +278,7 @@ void fri_pow_launch(const u64 state[12], int pos, u64 base, unsigned pow_bits, s
 // One block per query.  Writes, in proof order: for each initial oracle: leaf row + path; for each layer:
 // 16 extension values + path.
 __global__ __launch_bounds__(256) void k_gather_queries(QueryGatherArgs A) {
+  LATENCY_KERNEL_PRIO();
   const int q = blockIdx.x, t = threadIdx.x;
   u64* out = A.out + (size_t)q * A.words_per_query;
   size_t x_index = A.indices[q];

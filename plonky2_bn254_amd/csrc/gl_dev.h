@@ -12,6 +12,15 @@ typedef uint32_t u32;
 
 #define GL_HD __host__ __device__ __forceinline__
 
+// First statement of the latency-bound kernels (few waves, long dependent chains: doubling chains, scans, batch inversions,
+// small Merkle levels, FRI folds, proof-of-work search): their waves win the SIMD's issue arbitration against the waves of
+// another proof's GPU-filling kernel that runs beside them, so they finish in about their stand-alone time.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define LATENCY_KERNEL_PRIO() __builtin_amdgcn_s_setprio(3)
+#else
+#define LATENCY_KERNEL_PRIO() ((void)0)
+#endif
+
 static constexpr u64 GL_P = 0xFFFFFFFF00000001ULL;
 static constexpr u64 GL_EPS = 0xFFFFFFFFULL;
 static constexpr u64 GL_GEN = 0xc65c18b67785d900ULL;       // multiplicative generator = coset shift

@@ -58,6 +58,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
 }
 
 __global__ __launch_bounds__(256) void k_merkle_level(const u64* __restrict__ in, u64* __restrict__ out, size_t n_out) {
+  LATENCY_KERNEL_PRIO();
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_out) return;
   const ulonglong2* p = reinterpret_cast<const ulonglong2*>(in + 8 * i);
@@ -73,6 +74,7 @@ __global__ __launch_bounds__(256) void k_merkle_level(const u64* __restrict__ in
 static constexpr size_t COOP_MAX_NODES = 16384;  // above this a level fills the GPU with one-lane permutations anyway
 
 __global__ __launch_bounds__(256) void k_merkle_level_coop(const u64* __restrict__ in, u64* __restrict__ out, size_t n_out) {
+  LATENCY_KERNEL_PRIO();
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t node = t >> 4;
   const int l = (int)(t & 15);
@@ -84,6 +86,7 @@ __global__ __launch_bounds__(256) void k_merkle_level_coop(const u64* __restrict
 
 __global__ __launch_bounds__(256) void k_leaf_hash_coop(const u64* __restrict__ data, size_t leaf_stride, size_t elem_stride,
                                                         int leaf_len, size_t n_leaves, u64* __restrict__ digests) {
+  LATENCY_KERNEL_PRIO();
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t j = t >> 4;
   const int l = (int)(t & 15);

@@ -22,6 +22,7 @@
 // out[e] = in[e]^-1 (0 -> 0); each thread owns CH elements strided by the grid size.
 template <int CH>
 __global__ __launch_bounds__(64) void k_fq_batch_inv(const u64* __restrict__ in, u64* __restrict__ out, size_t count) {
+  LATENCY_KERNEL_PRIO();
   size_t T = (size_t)gridDim.x * blockDim.x, tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   fq v[CH], pre[CH];
   fq acc = fq_one();
@@ -49,6 +50,7 @@ __global__ __launch_bounds__(64) void k_fq_batch_inv(const u64* __restrict__ in,
 
 // Goldilocks inverses of counter and counter-511 for counter in [0,512): computed once per context.
 __global__ void k_round_flag_table(u64* tbl /* [2][512] */) {
+  LATENCY_KERNEL_PRIO();
   int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= 512) return;
   tbl[c] = c == 0 ? 0 : gl_inv((u64)c);
@@ -99,6 +101,7 @@ __global__ __launch_bounds__(1024) void k_histogram(const u64* __restrict__ trac
 }
 __global__ __launch_bounds__(256) void k_range_columns(u64* __restrict__ trace, size_t N, int freq_col, int range_col,
                                                        const u32* __restrict__ hist) {
+  LATENCY_KERNEL_PRIO();
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
   trace[(size_t)range_col * N + i] = i < 65536 ? i : 65535;
@@ -123,6 +126,7 @@ void launch_range_columns(u64* trace, size_t N, int rc_begin, int rc_end, int fr
 // ---- phase A: doubling chain (sequential) + running sums (parallel scan, chain_scan.h) -----------------------------
 __global__ __launch_bounds__(64) void k_g1_dbl_chain(const u64* __restrict__ xs, int n, u64* __restrict__ px, u64* __restrict__ py,
                                                      u64* __restrict__ pz) {
+  LATENCY_KERNEL_PRIO();
   int inst = blockIdx.x * blockDim.x + threadIdx.x;
   if (inst >= n) return;
   size_t cnt = (size_t)NPTS * n;
@@ -144,6 +148,7 @@ __global__ __launch_bounds__(64) void k_g1_dbl_chain(const u64* __restrict__ xs,
 __global__ __launch_bounds__(256) void k_g1_sum_scan(const u64* __restrict__ scalars, const u64* __restrict__ offs, int n,
                                                      u64* __restrict__ px, u64* __restrict__ py, u64* __restrict__ pz,
                                                      int* __restrict__ err) {
+  LATENCY_KERNEL_PRIO();
   __shared__ u64 sh[12 * 256];
   const int inst = blockIdx.x, k = threadIdx.x;
   const size_t cnt = (size_t)NPTS * n;
@@ -198,6 +203,7 @@ __device__ __forceinline__ AffPt affine_pt(const u64* px, const u64* py, const u
 __global__ __launch_bounds__(64) void k_g1_row_den(const u64* __restrict__ scalars, int n, const u64* __restrict__ px,
                                                    const u64* __restrict__ py, const u64* __restrict__ zi,
                                                    u64* __restrict__ den) {
+  LATENCY_KERNEL_PRIO();
   size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   size_t nrows = (size_t)n * 512;
   if (r >= nrows) return;
@@ -223,6 +229,7 @@ __global__ __launch_bounds__(64) void k_g1_rows(const u64* __restrict__ scalars,
                                                 const u64* __restrict__ py, const u64* __restrict__ zi,
                                                 const u64* __restrict__ deninv, const u64* __restrict__ rf_tbl,
                                                 u64* __restrict__ trace, size_t N, int* __restrict__ err) {
+  LATENCY_KERNEL_PRIO();
   size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   size_t nrows = (size_t)n * 512;
   if (r >= nrows) return;
@@ -349,6 +356,7 @@ __global__ __launch_bounds__(64) void k_g1_rows(const u64* __restrict__ scalars,
 // ---- final outputs: s*x + offset = S_255 in canonical affine form ------------------------------------------
 __global__ void k_g1_outputs(const u64* __restrict__ scalars, int n, const u64* __restrict__ px, const u64* __restrict__ py,
                              const u64* __restrict__ zi, u64* __restrict__ out8) {
+  LATENCY_KERNEL_PRIO();
   int inst = blockIdx.x * blockDim.x + threadIdx.x;
   if (inst >= n) return;
   u64 s[4];

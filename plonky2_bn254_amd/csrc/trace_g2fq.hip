@@ -36,6 +36,7 @@ __device__ __forceinline__ fq2 fq2_from_canonical(const u64* w) {
 // phase A as in trace_g1.hip: sequential doubling chain, then the running sums by a parallel scan (chain_scan.h)
 __global__ __launch_bounds__(64) void k_g2_dbl_chain(const u64* __restrict__ xs, int n, Soa2 px, Soa2 py, Soa2 pz,
                                                      u64* __restrict__ znorm) {
+  LATENCY_KERNEL_PRIO();
   int inst = blockIdx.x * blockDim.x + threadIdx.x;
   if (inst >= n) return;
   size_t cnt = (size_t)NPTS * n;
@@ -56,6 +57,7 @@ __global__ __launch_bounds__(64) void k_g2_dbl_chain(const u64* __restrict__ xs,
 
 __global__ __launch_bounds__(256) void k_g2_sum_scan(const u64* __restrict__ scalars, const u64* __restrict__ offs, int n, Soa2 px,
                                                      Soa2 py, Soa2 pz, u64* __restrict__ znorm, int* __restrict__ err) {
+  LATENCY_KERNEL_PRIO();
   __shared__ u64 sh[24 * 256];
   const int inst = blockIdx.x, k = threadIdx.x;
   const size_t cnt = (size_t)NPTS * n;
@@ -110,6 +112,7 @@ __device__ __forceinline__ Aff2 affine_pt2(const Soa2& px, const Soa2& py, const
 // per row: inv-input slots [0] = norm(den), [1] = dx.c0, [2] = dx.c1  (each an Fq SoA vector of nrows)
 __global__ __launch_bounds__(64) void k_g2_row_den(const u64* __restrict__ scalars, int n, Soa2 px, Soa2 py, Soa2 pz,
                                                    const u64* __restrict__ zni, u64* __restrict__ inv_in) {
+  LATENCY_KERNEL_PRIO();
   size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   size_t nrows = (size_t)n * 512;
   if (r >= nrows) return;
@@ -152,6 +155,7 @@ __global__ __launch_bounds__(64) void k_g2_rows(const u64* __restrict__ scalars,
                                                 const u64* __restrict__ zni, const u64* __restrict__ inv_out,
                                                 const u64* __restrict__ rf_tbl, u64* __restrict__ trace, size_t N,
                                                 int* __restrict__ err) {
+  LATENCY_KERNEL_PRIO();
   typedef G2L L;
   size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   size_t nrows = (size_t)n * 512;
@@ -305,6 +309,7 @@ __global__ __launch_bounds__(64) void k_g2_rows(const u64* __restrict__ scalars,
 
 __global__ void k_g2_outputs(const u64* __restrict__ scalars, int n, Soa2 px, Soa2 py, Soa2 pz, const u64* __restrict__ zni,
                              u64* __restrict__ out16) {
+  LATENCY_KERNEL_PRIO();
   int inst = blockIdx.x * blockDim.x + threadIdx.x;
   if (inst >= n) return;
   u64 s[4];
@@ -354,6 +359,7 @@ int g2_generate_trace_device(const u64* d_scalars, const u64* d_x, const u64* d_
 // table per instance: 0 = one, 1+k = C_k = P_{k-1} * x^(2^k), 257+k = x^(2^k)
 __global__ __launch_bounds__(64) void k_fq_chain(const u64* __restrict__ scalars, const u64* __restrict__ xs, int n,
                                                  u64* __restrict__ tab) {
+  LATENCY_KERNEL_PRIO();
   int inst = blockIdx.x * blockDim.x + threadIdx.x;
   if (inst >= n) return;
   size_t cnt = (size_t)NPTS * n;
@@ -374,6 +380,7 @@ __global__ __launch_bounds__(64) void k_fq_chain(const u64* __restrict__ scalars
 __global__ __launch_bounds__(64) void k_fq_rows(const u64* __restrict__ scalars, int n, const u64* __restrict__ tab,
                                                 const u64* __restrict__ rf_tbl, u64* __restrict__ trace, size_t N,
                                                 int* __restrict__ err) {
+  LATENCY_KERNEL_PRIO();
   typedef FQL L;
   size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   size_t nrows = (size_t)n * 512;
@@ -436,6 +443,7 @@ __global__ __launch_bounds__(64) void k_fq_rows(const u64* __restrict__ scalars,
 }
 
 __global__ void k_fq_outputs(const u64* __restrict__ scalars, int n, const u64* __restrict__ tab, u64* __restrict__ out4) {
+  LATENCY_KERNEL_PRIO();
   int inst = blockIdx.x * blockDim.x + threadIdx.x;
   if (inst >= n) return;
   u64 s[4];
