@@ -24,6 +24,7 @@ struct BufPool {
     }
     void* p = nullptr;
     if (hipMalloc(&p, bytes) != hipSuccess) {
+      (void)hipGetLastError();  // the failure is reported through the return value: do not leave it as the thread's sticky error
       err = "hipMalloc failed for " + name + " (" + std::to_string(bytes) + " bytes)";
       return nullptr;
     }

@@ -319,6 +319,7 @@ static int prove_on_slot(bn254s_ctx* c, Slot& sl, int kind, const bn254s_params&
   if (!d_hist || !d_in || !d_tvals || !d_tcoef || !d_tmp || !d_tlde || !d_trees || !d_avals || !d_acoef || !d_alde || !d_scr || !d_q ||
       !d_tabs || !d_open || !d_fri || !d_fritrees || !d_qout) {
     err = mem.err;
+    mem.release();  // a workspace that could not be completed is given back: the context stays usable for smaller proofs
     return BN254S_E_OOM;
   }
   int* d_err = (int*)(d_in + in_words);

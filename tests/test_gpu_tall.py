@@ -102,3 +102,15 @@ def test_fq_exp_2pow23_rows_one_proof(gpu_ctx):
         gpu_ctx.verify(2, bad, 23, s, x, None, pr.outputs)
     with pytest.raises(pk.VerifyError):
         pk.verify_host(2, bad, 23, s, x, None, pr.outputs)
+
+
+def test_out_of_memory_is_an_error_and_the_context_survives(gpu_ctx):
+    """A G2 proof of 2^23 rows needs about 370 GB even in the compact workspace: BN254S_E_OOM (-3), the partial workspace is
+    released and the context goes on proving."""
+    base = synth.g2_inputs(2, seed=71)
+    s, x, o = (np.repeat(a[:1], 16384, axis=0) for a in base)
+    with pytest.raises(RuntimeError, match="-3"):
+        gpu_ctx.prove_g2(s, x, o)
+    s2, x2 = synth.fq_inputs(3, seed=72)
+    pr = gpu_ctx.prove_fq_exp(s2, x2)
+    gpu_ctx.verify(2, pr.words, pr.degree_bits, s2, x2, None, pr.outputs)
