@@ -44,18 +44,11 @@ int orc_num_threads() {
   return 1;
 #endif
 }
-// The restatement stops scaling at a few dozen threads (its commitment phase is bound by strided gathers): callers that time
-// it (bench.py's cpu_baseline) pick the thread count and report it.
+// The restatement stops scaling at a few dozen threads: callers that time it (bench.py's cpu_baseline) pick the thread count
+// and report it.
 void orc_set_num_threads(int n) {
 #ifdef _OPENMP
   if (n > 0) omp_set_num_threads(n);
-#else
-  (void)n;
-#endif
-}
-void orc_set_num_threads(int n) {
-#ifdef _OPENMP
-  omp_set_num_threads(n);
 #else
   (void)n;
 #endif
