@@ -111,26 +111,19 @@ __device__ __forceinline__ void poseidon_mds(u64 s[12], const u64* __restrict__ 
   for (int i = 0; i < 12; i++) s[i] = out[i];
 }
 #else
+// host (the Fiat-Shamir transcript: ~700 dependent permutations per proof between kernel launches): one 64 x 8-bit product
+// per term into a 128-bit sum, one reduction per output lane (3.1 us per permutation; the 32-bit-halves form with rolled
+// loops took 7.2 us, i.e. 5 ms of host time on every proof's critical path)
 inline void poseidon_mds(u64 s[12]) {
-  const u32 C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
-  u64 lo[12], hi[12], out[12];
-  for (int i = 0; i < 12; i++) {
-    lo[i] = s[i] & GL_EPS;
-    hi[i] = s[i] >> 32;
-  }
+  static const u64 C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+  u64 t[24], out[12];
+  for (int i = 0; i < 12; i++) t[i] = t[i + 12] = s[i];
+#pragma unroll
   for (int r = 0; r < 12; r++) {
-    u64 al = 0, ah = 0;
-    for (int i = 0; i < 12; i++) {
-      al += lo[(i + r) % 12] * C[i];
-      ah += hi[(i + r) % 12] * C[i];
-    }
-    if (r == 0) {
-      al += lo[0] * 8;
-      ah += hi[0] * 8;
-    }
-    u64 l = al + (ah << 32);
-    u64 h = (ah >> 32) + (l < al ? 1 : 0);
-    out[r] = gl_reduce128(l, h);
+    unsigned __int128 acc = r == 0 ? (unsigned __int128)t[0] * 8 : 0;
+#pragma unroll
+    for (int i = 0; i < 12; i++) acc += (unsigned __int128)t[i + r] * C[i];
+    out[r] = gl_reduce128((u64)acc, (u64)(acc >> 64));
   }
   for (int i = 0; i < 12; i++) s[i] = out[i];
 }
@@ -195,8 +188,10 @@ GL_HD void poseidon_permute(u64 s[12]) {
 #endif
 #else
   for (int rnd = 0; rnd < 30; rnd++) {
+#pragma unroll
     for (int i = 0; i < 12; i++) s[i] = gl_add(s[i], poseidon_rc(12 * rnd + i));
     if (rnd < 4 || rnd >= 26) {
+#pragma unroll
       for (int i = 0; i < 12; i++) s[i] = poseidon_sbox(s[i]);
     } else {
       s[0] = poseidon_sbox(s[0]);
