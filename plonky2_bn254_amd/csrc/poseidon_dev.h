@@ -169,6 +169,64 @@ static __constant__ __attribute__((aligned(64))) u32 POSEIDON_BLK_DEV[7 * 15 * 1
 #include "poseidon_blocks.inc"
 };
 
+#if !defined(__HIP_DEVICE_COMPILE__)
+// Host permutation (the Fiat-Shamir transcript and the host verifier: ~620 dependent permutations per G1 proof on the
+// proof's critical path).  The 22 partial rounds run in their sparse form - one S-box, one 12-term dot product and eleven
+// multiply-adds per round instead of a dense 12 x 12 layer - followed by one dense 11 x 11 layer; tables and derivation:
+// tools/derive_poseidon_host_fast.py.  Same field elements as the textbook rounds (tests/test_oracle_poseidon.py,
+// tests/test_gpu_kernels.py compare it with the oracle's and the device's permutation).
+#include "poseidon_host_fast.inc"
+struct PoseidonDot {  // sum of up to 16 products of 64-bit values, reduced once
+  unsigned __int128 lo = 0, hi = 0;
+  inline void mad(u64 a, u64 b) {
+    const unsigned __int128 p = (unsigned __int128)a * b;
+    lo += (u64)p;
+    hi += (u64)(p >> 64);
+  }
+  inline u64 reduce() const {  // lo + 2^64 hi with 2^64 = EPS: below 2^101
+    const unsigned __int128 t = lo + hi * GL_EPS;
+    return gl_reduce128((u64)t, (u64)(t >> 64));
+  }
+};
+// x + c for the S-box input: any representative below 2^64 (gl_mul is exact for those)
+inline u64 poseidon_add_rc(u64 x, u64 c) {
+  const u64 t = x + c;
+  return t < x ? t + GL_EPS : t;
+}
+inline void poseidon_full_round_host(u64 s[12], const u64* rc) {
+#pragma unroll
+  for (int i = 0; i < 12; i++) s[i] = poseidon_sbox(poseidon_add_rc(s[i], rc[i]));
+  poseidon_mds(s);
+}
+inline void poseidon_permute_host(u64 s[12]) {
+  for (int rnd = 0; rnd < 4; rnd++) poseidon_full_round_host(s, POSEIDON_RC_HOST + 12 * rnd);
+  for (int t = 0; t < 22; t++) {
+    const u64 x0 = poseidon_sbox(poseidon_add_rc(s[0], PHF_K[t]));
+    const u64 *w = PHF_W + 11 * t, *u = PHF_U + 11 * t;
+    PoseidonDot d;
+    d.mad(x0, PHF_M00[t]);
+#pragma unroll
+    for (int i = 0; i < 11; i++) d.mad(w[i], s[i + 1]);
+#pragma unroll
+    for (int i = 0; i < 11; i++) {
+      const unsigned __int128 p = (unsigned __int128)u[i] * x0 + s[i + 1];
+      s[i + 1] = gl_reduce128((u64)p, (u64)(p >> 64));
+    }
+    s[0] = d.reduce();
+  }
+  u64 y[11];
+  for (int r = 0; r < 11; r++) {
+    PoseidonDot d;
+#pragma unroll
+    for (int i = 0; i < 11; i++) d.mad(PHF_DENSE[11 * r + i], s[i + 1]);
+    y[r] = d.reduce();
+  }
+  for (int r = 0; r < 11; r++) s[r + 1] = y[r];
+  poseidon_full_round_host(s, PHF_RC26M);
+  for (int rnd = 27; rnd < 30; rnd++) poseidon_full_round_host(s, POSEIDON_RC_HOST + 12 * rnd);
+}
+#endif
+
 // In place, canonical result.
 GL_HD void poseidon_permute(u64 s[12]) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -187,17 +245,7 @@ GL_HD void poseidon_permute(u64 s[12]) {
   for (int i = 0; i < 12; i++) s[i] = x[i] >= GL_P ? x[i] - GL_P : x[i];
 #endif
 #else
-  for (int rnd = 0; rnd < 30; rnd++) {
-#pragma unroll
-    for (int i = 0; i < 12; i++) s[i] = gl_add(s[i], poseidon_rc(12 * rnd + i));
-    if (rnd < 4 || rnd >= 26) {
-#pragma unroll
-      for (int i = 0; i < 12; i++) s[i] = poseidon_sbox(s[i]);
-    } else {
-      s[0] = poseidon_sbox(s[0]);
-    }
-    poseidon_mds(s);
-  }
+  poseidon_permute_host(s);
 #endif
 }
 

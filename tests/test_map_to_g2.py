@@ -111,3 +111,10 @@ def test_hash_to_fq2_host_function_matches_python():
         got = (synth.words_to_int(out[:4]), synth.words_to_int(out[4:]))
         assert got == m2g.hash_to_fq2(inp.tolist()), n
         assert got[0] < synth.P and got[1] < synth.P
+    # extreme digits through the host permutation's sparse partial rounds (tools/derive_poseidon_host_fast.py)
+    edge = [0, 1, m2g.GL_P - 1, (1 << 32) - 1, 1 << 32, m2g.GL_P - (1 << 32), 0xFFFFFFFF00000000]
+    for k in range(len(edge)):
+        inp = np.array([edge[(k + i) % len(edge)] for i in range(24)], dtype=np.uint64)
+        out = np.zeros(8, np.uint64)
+        assert lib.bn254s_hash_to_fq2(L._ptr(inp), inp.size, L._ptr(out)) == 0
+        assert (synth.words_to_int(out[:4]), synth.words_to_int(out[4:])) == m2g.hash_to_fq2(inp.tolist()), k
