@@ -16,6 +16,7 @@
 // The trace is written column-major (trace[c*N + row]), so consecutive lanes write consecutive words.
 #include "trace_common.h"
 #include "chain_scan.h"
+#include "chain_coop.h"
 #include "trace_g1.h"
 
 // ---- batched field inversion ------------------------------------------------------------------------------
@@ -141,6 +142,88 @@ __global__ __launch_bounds__(64) void k_g1_dbl_chain(const u64* __restrict__ xs,
     st_fq(py, cnt, e, D.y);
     st_fq(pz, cnt, e, D.z);
     if (k < 256) D = g1_double(D);
+  }
+}
+
+// Cooperative form of the chain: four lanes per instance, lane p computes the p-th product of a level, the sums between the
+// products are integer combinations with one reduction each (chain_coop.h), values travel through LDS:
+//   level 1   a = X^2            b = Y^2              Z' = (2Y) Z
+//   level 2   c = b^2            s = (X + b)^2        f = (3a)^2
+//   combine   X' = f + 4a + 4c - 4s                   w = 6s - 6a - 6c - f          (= d - X' with d = 2 (s - a - c))
+//   level 3   m = (3a) w
+//   combine   Y' = m - 8c
+// Same formulas as g1_double, every stored value canonical: the points are bit for bit those of k_g1_dbl_chain, in 3 products
+// + 2 reductions of latency per doubling instead of 7 products + 13 additions.
+namespace g1coop {
+using namespace chain_coop;
+enum { SX, SY, SZ, SA, SB, SC, SS, SF, SWW, SM, NSLOT };
+constexpr int INST_W = NSLOT * SLOT_W;
+// (fa S1 + ga S2) (fb T1 + gb T2): operands below 3p with limbs <= 3 (2^26 - 1)
+__device__ __forceinline__ fq product(const u32* g, int s1, int s2, u32 fa, u32 ga, int t1, int t2, u32 fb, u32 gb) {
+  const fq u = lds_ld(g, s1), v = lds_ld(g, s2), x = lds_ld(g, t1), y = lds_ld(g, t2);
+  fq A, B;
+#pragma unroll
+  for (int j = 0; j < FQ_NL; j++) {
+    A.l[j] = u.l[j] * fa + v.l[j] * ga;
+    B.l[j] = x.l[j] * fb + y.l[j] * gb;
+  }
+  return fq_mul(A, B);
+}
+}  // namespace g1coop
+
+__global__ __launch_bounds__(64) void k_g1_dbl_chain_coop(const u64* __restrict__ xs, int n, u64* __restrict__ px,
+                                                          u64* __restrict__ py, u64* __restrict__ pz) {
+  using namespace g1coop;
+  LATENCY_KERNEL_PRIO();
+  __shared__ __attribute__((aligned(16))) u32 lds[16 * INST_W];
+  const int lane = threadIdx.x, grp = lane >> 2, p = lane & 3;
+  const int inst_raw = blockIdx.x * 16 + grp;
+  const bool live = inst_raw < n;
+  const int inst = live ? inst_raw : n - 1;  // idle groups shadow the last instance and store nothing
+  u32* g = lds + grp * INST_W;
+  const size_t cnt = (size_t)NPTS * n;
+  if (p < 2) {
+    lds_st(g, p == 0 ? SX : SY, fq_from_canonical(xs + 8 * inst + 4 * p));
+  } else if (p == 2) {
+    lds_st(g, SZ, fq_one());
+  }
+  u64* const out = p == 0 ? px : p == 1 ? py : pz;
+  __syncthreads();
+#pragma unroll 1
+  for (int k = 0; k <= 256; k++) {
+    const size_t e = (size_t)(257 + k) * n + inst;
+    if (live && p < 3) st_fq(out, cnt, e, lds_ld(g, p));  // slots SX, SY, SZ = 0, 1, 2
+    if (k == 256) break;
+    {  // level 1 (lane 3 repeats lane 0)
+      const int sa = p == 1 || p == 2 ? SY : SX, sb = p == 1 ? SY : p == 2 ? SZ : SX;
+      const fq r = product(g, sa, sa, p == 2 ? 2u : 1u, 0u, sb, sb, 1u, 0u);
+      __syncthreads();
+      if (p < 3) lds_st(g, p == 0 ? SA : p == 1 ? SB : SZ, r);
+    }
+    __syncthreads();
+    {  // level 2: b b, (X + b)(X + b), (3a)(3a)
+      const int s1 = p == 1 ? SX : p == 2 ? SA : SB;
+      const u32 f = p == 2 ? 3u : 1u, gg = p == 1 ? 1u : 0u;
+      const fq r = product(g, s1, SB, f, gg, s1, SB, f, gg);
+      if (p < 3) lds_st(g, p == 0 ? SC : p == 1 ? SS : SF, r);  // the slots written are not read at this level
+    }
+    __syncthreads();
+    {  // X' = f + 4a + 4c - 4s (+ 4p) on lane 0, w = 6s - 6a - 6c - f (+ 13p) on lane 1
+      const bool w = p == 1;
+      const fq r = combine(g, SF, w ? -1 : 1, SA, w ? -6 : 4, SC, w ? -6 : 4, SS, w ? 6 : -4, w ? 13 : 4);
+      if (p < 2) lds_st(g, w ? SWW : SX, r);  // X is not read again in this doubling
+    }
+    __syncthreads();
+    {  // level 3: m = (3a) w
+      const fq r = product(g, SA, SA, 3u, 0u, SWW, SWW, 1u, 0u);
+      if (p == 0) lds_st(g, SM, r);
+    }
+    __syncthreads();
+    {  // Y' = m - 8c (+ 8p)
+      const fq r = combine(g, SM, 1, SC, -8, SC, 0, SC, 0, 8);
+      if (p == 0) lds_st(g, SY, r);
+    }
+    __syncthreads();
   }
 }
 
@@ -388,7 +471,11 @@ int g1_generate_trace_device(const u64* d_scalars, const u64* d_x, const u64* d_
   u32* hist = (u32*)(rf + 1024);
   if (nrows < N) hipMemsetAsync(d_trace, 0, (size_t)G1_W * N * 8, st);
   launch_round_flag_table(rf, st);
-  k_g1_dbl_chain<<<(unsigned)((n + 63) / 64), 64, 0, st>>>(d_x, (int)n, px, py, pz);
+  static const bool one_lane_chain = getenv("BN254S_G1_CHAIN_ONE_LANE") != nullptr;  // A/B measurements
+  if (one_lane_chain)
+    k_g1_dbl_chain<<<(unsigned)((n + 63) / 64), 64, 0, st>>>(d_x, (int)n, px, py, pz);
+  else
+    k_g1_dbl_chain_coop<<<(unsigned)((n + 15) / 16), 64, 0, st>>>(d_x, (int)n, px, py, pz);
   k_g1_sum_scan<<<(unsigned)n, 256, 0, st>>>(d_scalars, d_off, (int)n, px, py, pz, d_err);
   launch_fq_batch_inv(pz, zi, cnt, st);
   k_g1_row_den<<<(unsigned)((nrows + 63) / 64), 64, 0, st>>>(d_scalars, (int)n, px, py, zi, den);

@@ -10,6 +10,7 @@
 // then one lane per trace row.
 #include "trace_common.h"
 #include "chain_scan.h"
+#include "chain_coop.h"
 #include "trace_g2fq.h"
 
 // ======================================== G2 ==================================================================
@@ -52,6 +53,114 @@ __global__ __launch_bounds__(64) void k_g2_dbl_chain(const u64* __restrict__ xs,
     st_fq2(pz, cnt, e, D.z);
     st_fq(znorm, cnt, e, fq2_norm(D.z));
     if (k < 256) D = g2_double(D);
+  }
+}
+
+// ---- cooperative doubling chain: eight lanes per instance ----------------------------------------------------------
+// The chain is 256 dependent doublings; one lane per instance leaves 2 waves running 6.7 k instructions per doubling.  Here
+// lane (p, c) of an instance's group of eight computes component c of the p-th Fq2 product of a level (a component is ONE
+// two-product Montgomery reduction), values travel through LDS, and the sums between the products are evaluated as small
+// integer combinations with one reduction each:
+//   level 1   a = X^2            b = Y^2              Z' = (2Y) Z          n = |Z|^2 (lane (3, 0): the norm the inversion needs)
+//   level 2   c = b^2            s = (X + b)^2        f = (3a)^2
+//   combine   X' = f + 4a + 4c - 4s                   w = 6s - 6a - 6c - f          (= d - X' with d = 2 (s - a - c))
+//   level 3   m = (3a) w
+//   combine   Y' = m - 8c
+// Same formulas as g2_double, every stored value canonical: the chain's points are bit for bit those of k_g2_dbl_chain.
+namespace g2coop {
+using namespace chain_coop;
+enum { SX, SY, SZ, SA, SB, SC, SS, SF, SWW, SM, NSLOT };
+constexpr int INST_W = NSLOT * 2 * SLOT_W;  // dwords per instance
+
+// component c of (fa S1 + ga S2) (fb T1 + gb T2) over Fq2, or with plain = true the sum of the two component products
+// (the norm).  Operand components stay below 3p with limbs <= 3 (2^26 - 1): c0 = A0 B0 + A1 (6p - B1) <= 27 p^2.
+__device__ __forceinline__ fq product(const u32* g, int c, bool plain, int s1, int s2, u32 fa, u32 ga, int t1, int t2, u32 fb,
+                                      u32 gb) {
+  fq A0, A1, B0, B1;
+  {
+    const fq u0 = lds_ld(g, 2 * s1), u1 = lds_ld(g, 2 * s1 + 1), v0 = lds_ld(g, 2 * s2), v1 = lds_ld(g, 2 * s2 + 1);
+#pragma unroll
+    for (int j = 0; j < FQ_NL; j++) {
+      A0.l[j] = u0.l[j] * fa + v0.l[j] * ga;
+      A1.l[j] = u1.l[j] * fa + v1.l[j] * ga;
+    }
+  }
+  {
+    const fq u0 = lds_ld(g, 2 * t1), u1 = lds_ld(g, 2 * t1 + 1), v0 = lds_ld(g, 2 * t2), v1 = lds_ld(g, 2 * t2 + 1);
+#pragma unroll
+    for (int j = 0; j < FQ_NL; j++) {
+      B0.l[j] = u0.l[j] * fb + v0.l[j] * gb;
+      B1.l[j] = u1.l[j] * fb + v1.l[j] * gb;
+    }
+  }
+  const fq nB1 = fq_sub_lazy<6>(fq_zero(), B1);
+  fq P, Q;
+#pragma unroll
+  for (int j = 0; j < FQ_NL; j++) {
+    P.l[j] = c ? B1.l[j] : B0.l[j];
+    Q.l[j] = c ? B0.l[j] : (plain ? B1.l[j] : nB1.l[j]);
+  }
+  return fq_mul2(A0, P, A1, Q);
+}
+}  // namespace g2coop
+
+__global__ __launch_bounds__(64) void k_g2_dbl_chain_coop(const u64* __restrict__ xs, int n, Soa2 px, Soa2 py, Soa2 pz,
+                                                          u64* __restrict__ znorm) {
+  using namespace g2coop;
+  LATENCY_KERNEL_PRIO();
+  __shared__ __attribute__((aligned(16))) u32 lds[8 * INST_W];
+  const int lane = threadIdx.x, grp = lane >> 3, p = (lane >> 1) & 3, c = lane & 1;
+  const int inst_raw = blockIdx.x * 8 + grp;
+  const bool live = inst_raw < n;
+  const int inst = live ? inst_raw : n - 1;  // idle groups shadow the last instance and store nothing
+  u32* g = lds + grp * INST_W;
+  const size_t cnt = (size_t)NPTS * n;
+  if (p < 2) {
+    lds_st(g, 2 * (p == 0 ? SX : SY) + c, fq_from_canonical(xs + 16 * inst + 8 * p + 4 * c));
+  } else if (p == 2) {
+    lds_st(g, 2 * SZ + c, c ? fq_zero() : fq_one());
+  }
+  u64* const out = p == 0 ? (c ? px.c1 : px.c0) : p == 1 ? (c ? py.c1 : py.c0) : (c ? pz.c1 : pz.c0);
+  __syncthreads();
+#pragma unroll 1
+  for (int k = 0; k <= 256; k++) {
+    const size_t e = (size_t)(257 + k) * n + inst;
+    if (live && p < 3) st_fq(out, cnt, e, lds_ld(g, 2 * p + c));  // slots SX, SY, SZ = 0, 1, 2
+    {  // level 1
+      const int sa = p == 0 ? SX : p == 3 ? SZ : SY, sb = p == 0 ? SX : p == 1 ? SY : SZ;
+      const fq r = product(g, c, p == 3, sa, sa, p == 2 ? 2u : 1u, 0u, sb, sb, 1u, 0u);
+      __syncthreads();
+      if (p == 3) {
+        if (live && c == 0) st_fq(znorm, cnt, e, r);
+      } else {
+        lds_st(g, 2 * (p == 0 ? SA : p == 1 ? SB : SZ) + c, r);
+      }
+    }
+    if (k == 256) break;
+    __syncthreads();
+    {  // level 2: b b, (X + b)(X + b), (3a)(3a); the fourth pair repeats the first
+      const int s1 = p == 1 ? SX : p == 2 ? SA : SB, s2 = SB;
+      const u32 f = p == 2 ? 3u : 1u, gg = p == 1 ? 1u : 0u;
+      const fq r = product(g, c, false, s1, s2, f, gg, s1, s2, f, gg);
+      if (p < 3) lds_st(g, 2 * (p == 0 ? SC : p == 1 ? SS : SF) + c, r);  // written slots are not read at this level
+    }
+    __syncthreads();
+    {  // X' = f + 4a + 4c - 4s (pair 0, + 4p), w = 6s - 6a - 6c - f (pair 1, + 13p); the other pairs repeat pair 0
+      const bool w = p == 1;
+      const fq r = combine(g, 2 * SF + c, w ? -1 : 1, 2 * SA + c, w ? -6 : 4, 2 * SC + c, w ? -6 : 4, 2 * SS + c, w ? 6 : -4, w ? 13 : 4);
+      if (p < 2) lds_st(g, 2 * (w ? SWW : SX) + c, r);  // X is not read again in this doubling
+    }
+    __syncthreads();
+    {  // level 3: m = (3a) w
+      const fq r = product(g, c, false, SA, SA, 3u, 0u, SWW, SWW, 1u, 0u);
+      if (p == 0) lds_st(g, 2 * SM + c, r);
+    }
+    __syncthreads();
+    {  // Y' = m - 8c (+ 8p)
+      const fq r = combine(g, 2 * SM + c, 1, 2 * SC + c, -8, 2 * SC + c, 0, 2 * SC + c, 0, 8);
+      if (p == 0) lds_st(g, 2 * SY + c, r);
+    }
+    __syncthreads();
   }
 }
 
@@ -343,7 +452,11 @@ int g2_generate_trace_device(const u64* d_scalars, const u64* d_x, const u64* d_
   u32* hist = (u32*)take(65536 / 2);
   if (nrows < N) hipMemsetAsync(d_trace, 0, (size_t)G2L::W * N * 8, st);
   launch_round_flag_table(rf, st);
-  k_g2_dbl_chain<<<(unsigned)((n + 63) / 64), 64, 0, st>>>(d_x, (int)n, px, py, pz, znorm);
+  static const bool one_lane_chain = getenv("BN254S_G2_CHAIN_ONE_LANE") != nullptr;  // A/B measurements
+  if (one_lane_chain)
+    k_g2_dbl_chain<<<(unsigned)((n + 63) / 64), 64, 0, st>>>(d_x, (int)n, px, py, pz, znorm);
+  else
+    k_g2_dbl_chain_coop<<<(unsigned)((n + 7) / 8), 64, 0, st>>>(d_x, (int)n, px, py, pz, znorm);
   k_g2_sum_scan<<<(unsigned)n, 256, 0, st>>>(d_scalars, d_off, (int)n, px, py, pz, znorm, d_err);
   launch_fq_batch_inv(znorm, zni, cnt, st);
   k_g2_row_den<<<(unsigned)((nrows + 63) / 64), 64, 0, st>>>(d_scalars, (int)n, px, py, pz, zni, inv_in);
