@@ -104,6 +104,19 @@ int bn254s_prove_g1_batch(bn254s_ctx* ctx, const bn254s_params* params, const ui
 int bn254s_prove_batch(bn254s_ctx* ctx, int kind, const bn254s_params* params, const uint64_t* scalars, const uint64_t* x,
                        const uint64_t* offset, size_t n_total, size_t per_proof, bn254s_proof** proofs_out);
 
+/* The same call in two halves, for a caller that keeps the GPU fed: _begin queues the proofs of the batch on the context's
+ * worker threads and returns; _end waits for them and returns what bn254s_prove_batch would have (on an error every proof of
+ * the batch is freed and its slot in proofs_out is NULL).  Batches are served in the order of their _begin calls, up to eight
+ * proofs in flight in total, so the first proofs of the next batch run while the last ones of the current batch finish (the
+ * reference's callers do the same with rayon over independent circuits).  scalars / x / offset / proofs_out must stay valid
+ * until _end; every handle must be passed to _end exactly once, before bn254s_ctx_destroy.  bn254s_prove_batch is
+ * _begin followed by _end. */
+typedef struct bn254s_batch bn254s_batch;
+int bn254s_prove_batch_begin(bn254s_ctx* ctx, int kind, const bn254s_params* params, const uint64_t* scalars, const uint64_t* x,
+                             const uint64_t* offset, size_t n_total, size_t per_proof, bn254s_proof** proofs_out,
+                             bn254s_batch** handle);
+int bn254s_prove_batch_end(bn254s_batch* handle);
+
 /* Several GPUs from one process: proof i is proven by ctxs[i mod n_ctx] (one context per GPU); no inter-GPU traffic.
  * Same arguments and results as bn254s_prove_batch otherwise. */
 int bn254s_prove_batch_multi(bn254s_ctx** ctxs, size_t n_ctx, int kind, const bn254s_params* params, const uint64_t* scalars,

@@ -87,6 +87,7 @@ int bn254s_ctx_create(int device_id, bn254s_ctx** out) {
 void bn254s_ctx_destroy(bn254s_ctx* c) {
   if (!c) return;
   hipSetDevice(c->device);
+  c->workers.shutdown();  // finishes what is queued
   hipStreamSynchronize(c->stream);
   for (Slot* s : c->slots) {
     hipStreamSynchronize(s->st);

@@ -6,6 +6,9 @@
 #include <cstdio>
 #include <mutex>
 #include <condition_variable>
+#include <deque>
+#include <functional>
+#include <thread>
 #include <hip/hip_runtime.h>
 #include "../../include/bn254_stark.h"
 #include "gl_dev.h"
@@ -56,11 +59,59 @@ struct Slot {
 
 enum { BIG_NTT = 0, BIG_EXCL = 1, BIG_HASH = 2 };
 
+// The host threads that drive the slots: worker s owns slot s and runs the proofs queued by the batch entry points in
+// arrival order, across calls - the first proofs of the next batch start while the last proofs of the current one finish
+// (bn254s_prove_batch_begin / _end).  Started on first use, joined by bn254s_ctx_destroy.
+struct WorkPool {
+  std::mutex mu;
+  std::condition_variable cv;
+  std::deque<std::function<void(size_t)>> q;
+  std::vector<std::thread> th;
+  bool stop = false;
+  void start(size_t n, int device) {
+    std::lock_guard<std::mutex> lk(mu);
+    while (th.size() < n) {
+      const size_t s = th.size();
+      th.emplace_back([this, s, device]() {
+        (void)hipSetDevice(device);
+        for (;;) {
+          std::function<void(size_t)> f;
+          {
+            std::unique_lock<std::mutex> lk2(mu);
+            cv.wait(lk2, [&] { return stop || !q.empty(); });
+            if (q.empty()) return;  // stop requested and nothing left
+            f = std::move(q.front());
+            q.pop_front();
+          }
+          f(s);
+        }
+      });
+    }
+  }
+  void push(std::function<void(size_t)> f) {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      q.push_back(std::move(f));
+    }
+    cv.notify_one();
+  }
+  void shutdown() {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      stop = true;
+    }
+    cv.notify_all();
+    for (auto& t : th) t.join();
+    th.clear();
+  }
+};
+
 struct bn254s_ctx : BufPool {
   int device = 0;
   hipStream_t stream = nullptr;
   NttTables ntt;
   std::vector<Slot*> slots;
+  WorkPool workers;
   std::map<unsigned, NttTallTables*> tall;  // per log_n (+100: halves of a split transform)
   std::map<unsigned, NttSplitTables*> split;  // per log_n
   // The GPU-filling sections of the proofs in flight take turns through the semaphore below; latency-bound kernels

@@ -746,54 +746,104 @@ int bn254s_prove_g1(bn254s_ctx* c, const bn254s_params* params, const uint64_t* 
   return BN254S_OK;
 }
 
-int bn254s_prove_batch(bn254s_ctx* c, int kind, const bn254s_params* params, const uint64_t* scalars, const uint64_t* x,
-                       const uint64_t* off, size_t n_total, size_t per_proof, bn254s_proof** proofs_out) {
-  if (!c || kind < 0 || kind > 2 || !params || !scalars || !x || (kind != KIND_FQ && !off) || !proofs_out || n_total == 0 || per_proof == 0 ||
-      params->struct_size != sizeof(bn254s_params))
+// A batch in flight: proof i of the batch is one task of the context's worker pool (ctx.h WorkPool).
+struct bn254s_batch {
+  bn254s_ctx* c = nullptr;
+  int kind = 0;
+  bn254s_params params;
+  const u64 *scalars = nullptr, *x = nullptr, *off = nullptr;
+  size_t n_total = 0, per_proof = 0, n_proofs = 0;
+  bn254s_proof** out = nullptr;
+  std::mutex mu;
+  std::condition_variable cv;
+  size_t remaining = 0;
+  int first_rc = 0;
+  std::string err;
+};
+
+int bn254s_prove_batch_begin(bn254s_ctx* c, int kind, const bn254s_params* params, const uint64_t* scalars, const uint64_t* x,
+                             const uint64_t* off, size_t n_total, size_t per_proof, bn254s_proof** proofs_out,
+                             bn254s_batch** handle) {
+  if (!c || kind < 0 || kind > 2 || !params || !scalars || !x || (kind != KIND_FQ && !off) || !proofs_out || !handle || n_total == 0 ||
+      per_proof == 0 || params->struct_size != sizeof(bn254s_params))
     return BN254S_E_INVALID_ARG;
+  *handle = nullptr;
   const size_t n_proofs = (n_total + per_proof - 1) / per_proof;
   const size_t PW = point_words(kind);
   for (size_t i = 0; i < n_proofs; i++) proofs_out[i] = nullptr;
   HIP_TRY(c, hipSetDevice(c->device));
   size_t n_slots = 8;  // proofs in flight (one stream, host thread and workspace each; GPU_MAX_HW_QUEUES = 16 gives every stream its own hardware queue)
   if (const char* e = getenv("BN254S_SLOTS")) n_slots = std::max(1, atoi(e));
-  n_slots = std::min(n_slots, n_proofs);
   for (size_t s = 0; s < n_slots; s++)
     if (!c->slot(s)) return BN254S_E_HIP;
-  std::atomic<size_t> next(0);
-  std::atomic<int> first_rc(0);
-  std::vector<std::string> errs(n_slots);
-  std::vector<std::thread> th;
-  for (size_t s = 0; s < n_slots; s++)
-    th.emplace_back([&, s]() {
-      hipSetDevice(c->device);
-      for (;;) {
-        size_t i = next.fetch_add(1);
-        if (i >= n_proofs || first_rc.load() != 0) break;
-        size_t b = i * per_proof, cnt = std::min(per_proof, n_total - b);
-        bn254s_proof* pr = new bn254s_proof();
-        int rc = prove_on_slot(c, *c->slots[s], kind, *params, scalars + 4 * b, x + PW * b, off ? off + PW * b : nullptr, cnt, pr, errs[s]);
-        if (rc != BN254S_OK) {
-          hipStreamSynchronize(c->slots[s]->st);
-          delete pr;
-          int z = 0;
-          first_rc.compare_exchange_strong(z, rc);
-          break;
-        }
-        proofs_out[i] = pr;
+  c->workers.start(n_slots, c->device);
+  bn254s_batch* B = new bn254s_batch();
+  B->c = c;
+  B->kind = kind;
+  B->params = *params;
+  B->scalars = scalars;
+  B->x = x;
+  B->off = off;
+  B->n_total = n_total;
+  B->per_proof = per_proof;
+  B->n_proofs = n_proofs;
+  B->out = proofs_out;
+  B->remaining = n_proofs;
+  for (size_t i = 0; i < n_proofs; i++)
+    c->workers.push([B, i, PW](size_t s) {
+      bool skip;
+      {
+        std::lock_guard<std::mutex> lk(B->mu);
+        skip = B->first_rc != 0;  // an earlier proof of this batch failed: the call returns that error
       }
+      if (!skip) {
+        const size_t b = i * B->per_proof, cnt = std::min(B->per_proof, B->n_total - b);
+        bn254s_proof* pr = new bn254s_proof();
+        std::string err;
+        int rc = prove_on_slot(B->c, *B->c->slots[s], B->kind, B->params, B->scalars + 4 * b, B->x + PW * b,
+                               B->off ? B->off + PW * b : nullptr, cnt, pr, err);
+        if (rc != BN254S_OK) {
+          hipStreamSynchronize(B->c->slots[s]->st);
+          delete pr;
+          std::lock_guard<std::mutex> lk(B->mu);
+          if (B->first_rc == 0) {
+            B->first_rc = rc;
+            B->err = err;
+          }
+        } else {
+          B->out[i] = pr;
+        }
+      }
+      std::lock_guard<std::mutex> lk(B->mu);  // (notify under the lock: the waiter frees the batch)
+      if (--B->remaining == 0) B->cv.notify_all();
     });
-  for (auto& t : th) t.join();
-  if (int rc = first_rc.load()) {
-    for (auto& e : errs)
-      if (!e.empty()) c->err = e;
-    for (size_t i = 0; i < n_proofs; i++) {
-      delete proofs_out[i];
-      proofs_out[i] = nullptr;
-    }
-    return rc;
-  }
+  *handle = B;
   return BN254S_OK;
+}
+
+int bn254s_prove_batch_end(bn254s_batch* B) {
+  if (!B) return BN254S_E_INVALID_ARG;
+  {
+    std::unique_lock<std::mutex> lk(B->mu);
+    B->cv.wait(lk, [&] { return B->remaining == 0; });
+  }
+  const int rc = B->first_rc;
+  if (rc) {
+    B->c->err = B->err;
+    for (size_t i = 0; i < B->n_proofs; i++) {
+      delete B->out[i];
+      B->out[i] = nullptr;
+    }
+  }
+  delete B;
+  return rc;
+}
+
+int bn254s_prove_batch(bn254s_ctx* c, int kind, const bn254s_params* params, const uint64_t* scalars, const uint64_t* x,
+                       const uint64_t* off, size_t n_total, size_t per_proof, bn254s_proof** proofs_out) {
+  bn254s_batch* B = nullptr;
+  int rc = bn254s_prove_batch_begin(c, kind, params, scalars, x, off, n_total, per_proof, proofs_out, &B);
+  return rc != BN254S_OK ? rc : bn254s_prove_batch_end(B);
 }
 
 int bn254s_prove_g1_batch(bn254s_ctx* c, const bn254s_params* params, const uint64_t* scalars, const uint64_t* x,

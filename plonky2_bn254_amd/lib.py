@@ -53,6 +53,9 @@ def load_library():
     lib.bn254s_generate_trace.argtypes = [vp, C.c_int, vp, vp, vp, C.c_size_t, C.c_uint32, vp, vp]
     lib.bn254s_prove_g1_batch.argtypes = [vp, C.POINTER(Params), vp, vp, vp, C.c_size_t, C.c_size_t, C.POINTER(vp)]
     lib.bn254s_prove_batch.argtypes = [vp, C.c_int, C.POINTER(Params), vp, vp, vp, C.c_size_t, C.c_size_t, C.POINTER(vp)]
+    lib.bn254s_prove_batch_begin.argtypes = [vp, C.c_int, C.POINTER(Params), vp, vp, vp, C.c_size_t, C.c_size_t, C.POINTER(vp),
+                                             C.POINTER(vp)]
+    lib.bn254s_prove_batch_end.argtypes = [vp]
     lib.bn254s_prove_batch_multi.argtypes = [C.POINTER(vp), C.c_size_t, C.c_int, C.POINTER(Params), vp, vp, vp, C.c_size_t,
                                              C.c_size_t, C.POINTER(vp)]
     lib.bn254s_proof_words.argtypes = [vp, C.POINTER(U64P), C.POINTER(C.c_size_t)]
@@ -234,6 +237,11 @@ class Context:
                                                  per_proof, outs), "bn254s_prove_batch")
         return [Proof(self._lib, C.c_void_p(outs[i])) for i in range(k)]
 
+    def prove_batch_begin(self, kind, scalars, x, offset=None, per_proof=128, params: Optional[Params] = None):
+        """bn254s_prove_batch_begin: queues the batch and returns a handle; `handle.end()` waits and returns the proofs.  Batches
+        run in the order they were begun, so beginning the next one before ending the current one keeps the GPU busy."""
+        return BatchInFlight(self, kind, scalars, x, offset, per_proof, params or default_params())
+
     def verify(self, kind, words, degree_bits, scalars, x, offset, outputs, params: Optional[Params] = None):
         """Native `verify` (src/starks/common/verifier.rs:32-98 + CTL check): returns None or raises VerifyError(reason)."""
         params = params or default_params()
@@ -345,6 +353,35 @@ def verify_host(kind, words, degree_bits, scalars, x, offset, outputs, params: O
         raise VerifyError(buf.value.decode())
     if rc != 0:
         raise RuntimeError(f"bn254s_verify_host failed with {rc}: {buf.value.decode()}")
+
+
+class BatchInFlight:
+    """A batch between bn254s_prove_batch_begin and bn254s_prove_batch_end (keeps the input arrays alive meanwhile)."""
+
+    def __init__(self, ctx, kind, scalars, x, offset, per_proof, params):
+        self._ctx = ctx
+        self._keep = (scalars, x, offset, params)
+        n = scalars.shape[0]
+        self._k = (n + per_proof - 1) // per_proof
+        self._outs = (C.c_void_p * self._k)()
+        self._h = C.c_void_p()
+        ctx._check(ctx._lib.bn254s_prove_batch_begin(ctx._h, kind, C.byref(params), _ptr(scalars), _ptr(x), _ptr(offset), n, per_proof,
+                                                     self._outs, C.byref(self._h)), "bn254s_prove_batch_begin")
+
+    def end(self):
+        if self._h is None:
+            raise RuntimeError("batch already ended")
+        h, self._h = self._h, None
+        self._ctx._check(self._ctx._lib.bn254s_prove_batch_end(h), "bn254s_prove_batch_end")
+        self._keep = None
+        return [Proof(self._ctx._lib, C.c_void_p(self._outs[i])) for i in range(self._k)]
+
+    def __del__(self):
+        if getattr(self, "_h", None) is not None:  # never leave a batch running into freed inputs
+            try:
+                self.end()
+            except Exception:
+                pass
 
 
 def prove_batch_multi(contexts, kind, scalars, x, offset=None, per_proof=128, params: Optional[Params] = None):

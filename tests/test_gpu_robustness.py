@@ -136,3 +136,34 @@ def test_multi_context_batch_matches_single_context(gpu_ctx):
     del got
     a.close()
     b.close()
+
+
+def test_batches_in_flight_match_the_blocking_call(gpu_ctx):
+    """bn254s_prove_batch_begin / _end: two batches of different kinds open at the same time come back in order and equal to the
+    blocking call; a batch with a bad point fails in _end with the error code, the batch begun after it is unaffected and the
+    context keeps working."""
+    s, x, o = synth.g1_inputs(128 * 3 + 7, seed=41)
+    fs, fx = synth.fq_inputs(128 + 3, seed=43)
+    ref_g1 = [p.words.copy() for p in gpu_ctx.prove_g1_batch(s, x, o)]
+    ref_fq = [p.words.copy() for p in gpu_ctx.prove_batch(2, fs, fx)]
+    h1 = gpu_ctx.prove_batch_begin(0, s, x, o)
+    h2 = gpu_ctx.prove_batch_begin(2, fs, fx)
+    h3 = gpu_ctx.prove_batch_begin(0, s[:130], x[:130], o[:130])
+    got_g1, got_fq, got_3 = h1.end(), h2.end(), h3.end()
+    assert [len(got_g1), len(got_fq), len(got_3)] == [4, 2, 2]
+    for g, r in zip(got_g1, ref_g1):
+        assert np.array_equal(g.words, r)
+    for g, r in zip(got_fq, ref_fq):
+        assert np.array_equal(g.words, r)
+    assert np.array_equal(got_3[0].words, ref_g1[0])
+    with pytest.raises(RuntimeError, match="already ended"):
+        h1.end()
+    bad_o = o.copy()
+    bad_o[130] = neg_point_words(x[130])
+    hb = gpu_ctx.prove_batch_begin(0, s, x, bad_o)
+    hg = gpu_ctx.prove_batch_begin(0, s[:128], x[:128], o[:128])
+    with pytest.raises(RuntimeError, match="-4"):
+        hb.end()
+    good = hg.end()
+    assert np.array_equal(good[0].words, ref_g1[0])
+    assert np.array_equal(gpu_ctx.prove_g1(s[:128], x[:128], o[:128]).words, ref_g1[0])
