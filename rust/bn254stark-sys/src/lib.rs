@@ -26,6 +26,10 @@ pub struct Bn254sCtx {
 pub struct Bn254sProof {
     _p: [u8; 0],
 }
+#[repr(C)]
+pub struct Bn254sBatch {
+    _p: [u8; 0],
+}
 
 pub const BN254S_OK: c_int = 0;
 pub const BN254S_E_INVALID_POINT: c_int = -4;
@@ -66,6 +70,10 @@ extern "C" {
                               x: *const u64, offset: *const u64, n_total: usize, per_proof: usize,
                               proofs: *mut *mut Bn254sProof) -> c_int;
     /// one context per GPU, proof i on context i mod n_ctx
+    pub fn bn254s_prove_batch_begin(ctx: *mut Bn254sCtx, kind: c_int, params: *const Bn254sParams, scalars: *const u64,
+                                    x: *const u64, offset: *const u64, n_total: usize, per_proof: usize,
+                                    proofs_out: *mut *mut Bn254sProof, handle: *mut *mut Bn254sBatch) -> c_int;
+    pub fn bn254s_prove_batch_end(handle: *mut Bn254sBatch) -> c_int;
     pub fn bn254s_prove_batch_multi(ctxs: *mut *mut Bn254sCtx, n_ctx: usize, kind: c_int, params: *const Bn254sParams,
                                     scalars: *const u64, x: *const u64, offset: *const u64, n_total: usize,
                                     per_proof: usize, proofs: *mut *mut Bn254sProof) -> c_int;
