@@ -59,31 +59,37 @@ struct Slot {
 
 enum { BIG_NTT = 0, BIG_EXCL = 1, BIG_HASH = 2 };
 
-// The host threads that drive the slots: worker s owns slot s and runs the proofs queued by the batch entry points in
-// arrival order, across calls - the first proofs of the next batch start while the last proofs of the current one finish
+// The host threads that drive the slots: a worker takes the next proof queued by the batch entry points (arrival order, across
+// calls) and the lowest free slot - the first proofs of the next batch start while the last proofs of the current one finish
 // (bn254s_prove_batch_begin / _end).  Started on first use, joined by bn254s_ctx_destroy.
 struct WorkPool {
   std::mutex mu;
   std::condition_variable cv;
   std::deque<std::function<void(size_t)>> q;
   std::vector<std::thread> th;
+  std::vector<char> busy;  // per slot; a task runs on the LOWEST free slot, so k proofs in flight only ever touch slots 0..k-1
   bool stop = false;
   void start(size_t n, int device) {
     std::lock_guard<std::mutex> lk(mu);
+    if (busy.size() < n) busy.resize(n, 0);
     while (th.size() < n) {
-      const size_t s = th.size();
-      th.emplace_back([this, s, device]() {
+      th.emplace_back([this, device]() {
         (void)hipSetDevice(device);
         for (;;) {
           std::function<void(size_t)> f;
+          size_t s = 0;
           {
             std::unique_lock<std::mutex> lk2(mu);
             cv.wait(lk2, [&] { return stop || !q.empty(); });
             if (q.empty()) return;  // stop requested and nothing left
             f = std::move(q.front());
             q.pop_front();
+            while (busy[s]) s++;  // as many slots as workers: one is free
+            busy[s] = 1;
           }
           f(s);
+          std::lock_guard<std::mutex> lk3(mu);
+          busy[s] = 0;
         }
       });
     }
@@ -94,6 +100,13 @@ struct WorkPool {
       q.push_back(std::move(f));
     }
     cv.notify_one();
+  }
+  // calls g(i) for every slot that is idle right now (no task can start meanwhile)
+  template <class G>
+  void for_idle_slots(G g) {
+    std::lock_guard<std::mutex> lk(mu);
+    for (size_t i = 0; i < busy.size(); i++)
+      if (!busy[i]) g(i);
   }
   void shutdown() {
     {

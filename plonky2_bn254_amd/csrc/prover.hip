@@ -802,6 +802,16 @@ int bn254s_prove_batch_begin(bn254s_ctx* c, int kind, const bn254s_params* param
         std::string err;
         int rc = prove_on_slot(B->c, *B->c->slots[s], B->kind, B->params, B->scalars + 4 * b, B->x + PW * b,
                                B->off ? B->off + PW * b : nullptr, cnt, pr, err);
+        if (rc == BN254S_E_OOM) {
+          // the workspaces other slots keep from earlier (smaller or differently shaped) proofs may be what is in the way:
+          // give back those of the idle slots and try once more
+          B->c->workers.for_idle_slots([&](size_t i) {
+            if (i < B->c->slots.size()) B->c->slots[i]->mem.release();
+          });
+          err.clear();
+          rc = prove_on_slot(B->c, *B->c->slots[s], B->kind, B->params, B->scalars + 4 * b, B->x + PW * b,
+                             B->off ? B->off + PW * b : nullptr, cnt, pr, err);
+        }
         if (rc != BN254S_OK) {
           hipStreamSynchronize(B->c->slots[s]->st);
           delete pr;

@@ -114,3 +114,9 @@ def test_out_of_memory_is_an_error_and_the_context_survives(gpu_ctx):
     s2, x2 = synth.fq_inputs(3, seed=72)
     pr = gpu_ctx.prove_fq_exp(s2, x2)
     gpu_ctx.verify(2, pr.words, pr.degree_bits, s2, x2, None, pr.outputs)
+    # the same through the batch entry point (worker pool: the idle slots' workspaces are given back and the proof is tried
+    # once more before the error is returned)
+    with pytest.raises(RuntimeError, match="-3"):
+        gpu_ctx.prove_batch(1, s, x, o, per_proof=16384)
+    pr = gpu_ctx.prove_batch(2, s2, x2)[0]
+    gpu_ctx.verify(2, pr.words, pr.degree_bits, s2, x2, None, pr.outputs)
