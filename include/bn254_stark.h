@@ -106,7 +106,7 @@ int bn254s_prove_batch(bn254s_ctx* ctx, int kind, const bn254s_params* params, c
 
 /* The same call in two halves, for a caller that keeps the GPU fed: _begin queues the proofs of the batch on the context's
  * worker threads and returns; _end waits for them and returns what bn254s_prove_batch would have (on an error every proof of
- * the batch is freed and its slot in proofs_out is NULL).  Batches are served in the order of their _begin calls, up to eight
+ * the batch is freed and its slot in proofs_out is NULL).  Batches are served in the order of their _begin calls, up to twelve
  * proofs in flight in total, so the first proofs of the next batch run while the last ones of the current batch finish (the
  * reference's callers do the same with rayon over independent circuits).  scalars / x / offset / proofs_out must stay valid
  * until _end; every handle must be passed to _end exactly once, before bn254s_ctx_destroy.  bn254s_prove_batch is

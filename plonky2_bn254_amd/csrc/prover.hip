@@ -772,7 +772,10 @@ int bn254s_prove_batch_begin(bn254s_ctx* c, int kind, const bn254s_params* param
   const size_t PW = point_words(kind);
   for (size_t i = 0; i < n_proofs; i++) proofs_out[i] = nullptr;
   HIP_TRY(c, hipSetDevice(c->device));
-  size_t n_slots = 8;  // proofs in flight (one stream, host thread and workspace each; GPU_MAX_HW_QUEUES = 16 gives every stream its own hardware queue)
+  // proofs in flight (one stream, host thread and workspace each; GPU_MAX_HW_QUEUES = 16 gives every stream its own hardware
+  // queue).  With batches queued back to back (bench.py: two steps open) 8 / 10 / 12 / 14 / 16 slots give 81.0 / 83.0 / 84.0-84.7 /
+  // 85.0 / 84.3 proofs/s; one batch of eight proofs alone uses eight of them.
+  size_t n_slots = 12;
   if (const char* e = getenv("BN254S_SLOTS")) n_slots = std::max(1, atoi(e));
   for (size_t s = 0; s < n_slots; s++)
     if (!c->slot(s)) return BN254S_E_HIP;
