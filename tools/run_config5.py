@@ -20,7 +20,7 @@ u = np.array([synth._to_words(a[0]) + synth._to_words(a[1]) for a in us], dtype=
 # random non-infinity offsets (set_random_g2): 128 distinct points, tiled (python G2 arithmetic is slow)
 _, _, base_off = synth.g2_inputs(min(n, 128), seed=0x706C6F6E6B7932 + 5)
 off = np.tile(base_off, ((n + base_off.shape[0] - 1) // base_off.shape[0], 1))[:n].copy()
-ctx.map_to_g2(u[:1024], off[:1024])  # warm-up (tables, and the workspaces of all eight slots for both kinds)
+ctx.map_to_g2(u[:2048], off[:2048])  # warm-up (tables, and the workspaces of all twelve slots for both kinds: 16 G2 proofs)
 t0 = time.time()
 out, fq_jobs, g2_jobs, pf, pg = ctx.map_to_g2(u, off)
 dt = time.time() - t0
