@@ -69,8 +69,10 @@ struct WorkPool {
   std::vector<std::thread> th;
   std::vector<char> busy;  // per slot; a task runs on the LOWEST free slot, so k proofs in flight only ever touch slots 0..k-1
   bool stop = false;
+  size_t limit = 0, n_busy = 0;  // proofs in flight <= limit (BN254S_SLOTS of the latest batch call)
   void start(size_t n, int device) {
     std::lock_guard<std::mutex> lk(mu);
+    limit = n;
     if (busy.size() < n) busy.resize(n, 0);
     while (th.size() < n) {
       th.emplace_back([this, device]() {
@@ -80,16 +82,21 @@ struct WorkPool {
           size_t s = 0;
           {
             std::unique_lock<std::mutex> lk2(mu);
-            cv.wait(lk2, [&] { return stop || !q.empty(); });
+            cv.wait(lk2, [&] { return (stop && q.empty()) || (!q.empty() && n_busy < limit); });
             if (q.empty()) return;  // stop requested and nothing left
             f = std::move(q.front());
             q.pop_front();
-            while (busy[s]) s++;  // as many slots as workers: one is free
+            while (busy[s]) s++;  // n_busy < limit <= slots: one is free
             busy[s] = 1;
+            n_busy++;
           }
           f(s);
-          std::lock_guard<std::mutex> lk3(mu);
-          busy[s] = 0;
+          {
+            std::lock_guard<std::mutex> lk3(mu);
+            busy[s] = 0;
+            n_busy--;
+          }
+          cv.notify_one();  // a worker may be waiting for a free slot below the limit
         }
       });
     }
