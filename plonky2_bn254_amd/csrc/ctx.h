@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <mutex>
 #include <condition_variable>
+#include <chrono>
 #include <deque>
 #include <functional>
 #include <thread>
@@ -64,12 +65,13 @@ enum { BIG_NTT = 0, BIG_EXCL = 1, BIG_HASH = 2 };
 // (bn254s_prove_batch_begin / _end).  Started on first use, joined by bn254s_ctx_destroy.
 struct WorkPool {
   std::mutex mu;
-  std::condition_variable cv;
+  std::condition_variable cv, done_cv;
   std::deque<std::function<void(size_t)>> q;
   std::vector<std::thread> th;
   std::vector<char> busy;  // per slot; a task runs on the LOWEST free slot, so k proofs in flight only ever touch slots 0..k-1
   bool stop = false;
   size_t limit = 0, n_busy = 0;  // proofs in flight <= limit (BN254S_SLOTS of the latest batch call)
+  size_t n_waiting = 0, completions = 0;
   void start(size_t n, int device) {
     std::lock_guard<std::mutex> lk(mu);
     limit = n;
@@ -95,8 +97,10 @@ struct WorkPool {
             std::lock_guard<std::mutex> lk3(mu);
             busy[s] = 0;
             n_busy--;
+            completions++;
           }
           cv.notify_one();  // a worker may be waiting for a free slot below the limit
+          done_cv.notify_all();
         }
       });
     }
@@ -114,6 +118,19 @@ struct WorkPool {
     std::lock_guard<std::mutex> lk(mu);
     for (size_t i = 0; i < busy.size(); i++)
       if (!busy[i]) g(i);
+  }
+  // tasks that are running and not parked in wait_for_a_completion (the caller counts itself)
+  size_t active() {
+    std::lock_guard<std::mutex> lk(mu);
+    return n_busy - n_waiting;
+  }
+  // parks the calling task until another task ends (or a minute passes)
+  void wait_for_a_completion() {
+    std::unique_lock<std::mutex> lk(mu);
+    const size_t c0 = completions;
+    n_waiting++;
+    done_cv.wait_for(lk, std::chrono::seconds(60), [&] { return completions != c0; });
+    n_waiting--;
   }
   void shutdown() {
     {

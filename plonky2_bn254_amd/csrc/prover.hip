@@ -805,15 +805,19 @@ int bn254s_prove_batch_begin(bn254s_ctx* c, int kind, const bn254s_params* param
         std::string err;
         int rc = prove_on_slot(B->c, *B->c->slots[s], B->kind, B->params, B->scalars + 4 * b, B->x + PW * b,
                                B->off ? B->off + PW * b : nullptr, cnt, pr, err);
-        if (rc == BN254S_E_OOM) {
-          // the workspaces other slots keep from earlier (smaller or differently shaped) proofs may be what is in the way:
-          // give back those of the idle slots and try once more
+        // Out of device memory: the workspaces the idle slots keep from earlier (smaller or differently shaped) proofs may be
+        // what is in the way - give those back and try again; while other proofs are still running, wait for one of them to
+        // finish and repeat (a batch of tall proofs then runs as many at a time as fit).  Alone and still too large: the error.
+        while (rc == BN254S_E_OOM) {
           B->c->workers.for_idle_slots([&](size_t i) {
             if (i < B->c->slots.size()) B->c->slots[i]->mem.release();
           });
+          const bool last = B->c->workers.active() <= 1;  // nobody else is running: nothing more will be given back
           err.clear();
           rc = prove_on_slot(B->c, *B->c->slots[s], B->kind, B->params, B->scalars + 4 * b, B->x + PW * b,
                              B->off ? B->off + PW * b : nullptr, cnt, pr, err);
+          if (rc != BN254S_E_OOM || last) break;
+          B->c->workers.wait_for_a_completion();
         }
         if (rc != BN254S_OK) {
           hipStreamSynchronize(B->c->slots[s]->st);

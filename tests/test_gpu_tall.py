@@ -120,3 +120,20 @@ def test_out_of_memory_is_an_error_and_the_context_survives(gpu_ctx):
         gpu_ctx.prove_batch(1, s, x, o, per_proof=16384)
     pr = gpu_ctx.prove_batch(2, s2, x2)[0]
     gpu_ctx.verify(2, pr.words, pr.degree_bits, s2, x2, None, pr.outputs)
+
+
+def test_batch_of_tall_proofs_larger_than_memory_runs_as_many_at_a_time_as_fit(gpu_ctx):
+    """Ten G2 proofs of 1024 instances (2^19 rows, ~35 GB of workspace each) in one batch: more than the device holds with every
+    slot busy, so proofs that find no memory give back idle workspaces, wait for a running proof to finish and try again; the
+    batch completes and its proofs verify."""
+    base = synth.g2_inputs(64, seed=81)
+    s, x, o = (np.tile(a, (160, 1)) for a in base)      # 10240 instances
+    proofs = gpu_ctx.prove_batch(1, s, x, o, per_proof=1024)
+    assert len(proofs) == 10 and all(p.degree_bits == 19 for p in proofs)
+    for j in (0, 9):
+        sl = slice(1024 * j, 1024 * (j + 1))
+        gpu_ctx.verify(1, proofs[j].words, 19, s[sl], x[sl], o[sl], proofs[j].outputs)
+    # the context goes back to small proofs afterwards
+    s2, x2 = synth.fq_inputs(3, seed=82)
+    pr = gpu_ctx.prove_batch(2, s2, x2)[0]
+    gpu_ctx.verify(2, pr.words, pr.degree_bits, s2, x2, None, pr.outputs)
