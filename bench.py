@@ -93,7 +93,7 @@ def gather_caps(local_caps: np.ndarray, dist, device):
 def cpu_baseline():
     """Times ONE 128-instance proof with the CPU oracle (same algorithm, OpenMP) on the host cores."""
     from tests import oracle_lib
-    from plonky2_bn254_amd import synth
+    from tools import synth
     lib = oracle_lib.load()
     # the restatement is fastest at 24-48 threads on the 256-thread hosts of the pool (10.3 s against 20 s with all of them)
     if hasattr(lib, "orc_set_num_threads"):
@@ -353,7 +353,7 @@ def run_g1(args, pk, torch, synth, ctx, rank, world, dist, device, gather_device
 def map_to_g2_inputs(lo: int, hi: int):
     """Inputs [lo, hi) of the global 4096-input batch of configs[4]: uniform Fq2 elements u (xoshiro stream of
     tools/map_to_g2_ref.inputs) and non-infinity G2 offsets (128 distinct synthetic points, tiled by global index)."""
-    from plonky2_bn254_amd import synth
+    from tools import synth
     from tools import map_to_g2_ref as m2g
     us = m2g.inputs(hi)[lo:hi]
     u = np.array([synth._to_words(a[0]) + synth._to_words(a[1]) for a in us], dtype=np.uint64).reshape(hi - lo, 8)
@@ -451,7 +451,7 @@ def main():
 
     import plonky2_bn254_amd as pk   # first: sets GPU_MAX_HW_QUEUES before the HIP runtime initialises
     import torch
-    from plonky2_bn254_amd import synth
+    from tools import synth
 
     rank, local_rank, world, dist = init_dist(args)
     dev_id = int(os.environ.get("BENCH_DEVICE", local_rank))

@@ -29,7 +29,12 @@
  *
  * Errors: every function returns 0 on success or a negative BN254S_E_* code; the reference panics
  * (unwrap at stark_proof.rs:163,172), the Rust shim maps non-zero to panic!.
- * Threading: one call at a time per context; any number of contexts (one per GPU / per host thread).
+ * Threading: one call at a time per context (one host thread enters the context at a time); any number of contexts (one per
+ * GPU / per host thread).  A batch opened with bn254s_prove_batch_begin stays in flight after _begin returns: until its _end
+ * the context may still be entered, one call at a time, and every proving entry point (bn254s_prove_g1 / _g2 / _fq_exp /
+ * _batch* / bn254s_map_to_g2) queues behind the open batches on the same worker pool and runs on a free slot (stream +
+ * workspace) of its own, so it can never share device state with a proof of the open batch; bn254s_verify, _commit_values,
+ * _generate_trace and the _bench_* calls use the context's own stream and buffers and are independent of open batches.
  */
 #ifndef BN254_STARK_H
 #define BN254_STARK_H
@@ -84,6 +89,10 @@ int bn254s_abi_version(void);
 int bn254s_ctx_create(int device_id, bn254s_ctx** out);
 void bn254s_ctx_destroy(bn254s_ctx* ctx);
 const char* bn254s_last_error(const bn254s_ctx* ctx);
+/* Gives the device memory of every idle slot back to the driver (a slot = stream + workspace of one proof in flight; the
+ * workspaces are grow-only otherwise: after a 2^23-row proof slot 0 keeps ~245 GB).  Slots that are proving right now are left
+ * alone.  The next proof on a trimmed slot allocates its workspace again (a few ms). */
+int bn254s_ctx_trim(bn254s_ctx* ctx);
 
 /* Prove n G1 scalar multiplications s_i * x_i + offset_i in ONE STARK (timestamps 0..n-1), like
  * G1ScalarMulStark::generate_trace + prove (scalar_mul_stark.rs:55-69, common/prover.rs:18-72).
@@ -110,7 +119,8 @@ int bn254s_prove_batch(bn254s_ctx* ctx, int kind, const bn254s_params* params, c
  * proofs in flight in total, so the first proofs of the next batch run while the last ones of the current batch finish (the
  * reference's callers do the same with rayon over independent circuits).  scalars / x / offset / proofs_out must stay valid
  * until _end; every handle must be passed to _end exactly once, before bn254s_ctx_destroy.  bn254s_prove_batch is
- * _begin followed by _end. */
+ * _begin followed by _end, and the single-proof entry points are a batch of one proof: all of them may be called while
+ * handles are open (see "Threading" at the top). */
 typedef struct bn254s_batch bn254s_batch;
 int bn254s_prove_batch_begin(bn254s_ctx* ctx, int kind, const bn254s_params* params, const uint64_t* scalars, const uint64_t* x,
                              const uint64_t* offset, size_t n_total, size_t per_proof, bn254s_proof** proofs_out,

@@ -111,6 +111,20 @@ void bn254s_ctx_destroy(bn254s_ctx* c) {
   delete c;
 }
 
+int bn254s_ctx_trim(bn254s_ctx* c) {
+  if (!c) return BN254S_E_INVALID_ARG;
+  HIP_TRY(c, hipSetDevice(c->device));
+  auto give_back = [&](size_t i) {
+    if (i < c->n_slots_now()) c->slot(i)->mem.release();
+  };
+  if (c->workers.busy.empty()) {  // no batch call yet: no worker can be running
+    for (size_t i = 0; i < c->n_slots_now(); i++) give_back(i);
+  } else {
+    c->workers.for_idle_slots(give_back);
+  }
+  return BN254S_OK;
+}
+
 const char* bn254s_last_error(const bn254s_ctx* c) { return c ? c->err.c_str() : "null context"; }
 
 int bn254s_commit_values(bn254s_ctx* c, const uint64_t* values, size_t ncols, uint64_t* coeffs, uint64_t* lde,

@@ -72,6 +72,7 @@ struct WorkPool {
   bool stop = false;
   size_t limit = 0, n_busy = 0;  // proofs in flight <= limit (BN254S_SLOTS of the latest batch call)
   size_t n_waiting = 0, completions = 0;
+  std::mutex retry_mu;  // one task at a time gives idle workspaces back and allocates again after BN254S_E_OOM
   void start(size_t n, int device) {
     std::lock_guard<std::mutex> lk(mu);
     limit = n;
@@ -84,11 +85,16 @@ struct WorkPool {
           size_t s = 0;
           {
             std::unique_lock<std::mutex> lk2(mu);
-            cv.wait(lk2, [&] { return (stop && q.empty()) || (!q.empty() && n_busy < limit); });
+            auto free_slot = [&]() -> size_t {  // lowest slot that is neither running a task nor claimed by for_idle_slots
+              for (size_t i = 0; i < limit && i < busy.size(); i++)
+                if (!busy[i]) return i;
+              return (size_t)-1;
+            };
+            cv.wait(lk2, [&] { return (stop && q.empty()) || (!q.empty() && n_busy < limit && free_slot() != (size_t)-1); });
             if (q.empty()) return;  // stop requested and nothing left
             f = std::move(q.front());
             q.pop_front();
-            while (busy[s]) s++;  // n_busy < limit <= slots: one is free
+            s = free_slot();
             busy[s] = 1;
             n_busy++;
           }
@@ -112,22 +118,40 @@ struct WorkPool {
     }
     cv.notify_one();
   }
-  // calls g(i) for every slot that is idle right now (no task can start meanwhile)
+  // calls g(i) for every slot that is idle right now.  The idle slots are marked busy while g runs, so no task can start on
+  // one of them meanwhile, and g (hipFree: it synchronises the device) runs OUTSIDE the pool's mutex: running tasks finish and
+  // queue as usual.
   template <class G>
   void for_idle_slots(G g) {
-    std::lock_guard<std::mutex> lk(mu);
-    for (size_t i = 0; i < busy.size(); i++)
-      if (!busy[i]) g(i);
+    std::vector<size_t> idle;
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      for (size_t i = 0; i < busy.size(); i++)
+        if (!busy[i]) {
+          busy[i] = 2;  // claimed (not a running task: n_busy is unchanged)
+          idle.push_back(i);
+        }
+    }
+    for (size_t i : idle) g(i);
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      for (size_t i : idle) busy[i] = 0;
+    }
+    cv.notify_all();
   }
   // tasks that are running and not parked in wait_for_a_completion (the caller counts itself)
   size_t active() {
     std::lock_guard<std::mutex> lk(mu);
     return n_busy - n_waiting;
   }
-  // parks the calling task until another task ends (or a minute passes)
-  void wait_for_a_completion() {
+  size_t completions_now() {
+    std::lock_guard<std::mutex> lk(mu);
+    return completions;
+  }
+  // parks the calling task until a task has ended since `c0` was sampled (completions_now() BEFORE the failed attempt: a
+  // completion between the attempt and this call is not lost), or a minute has passed
+  void wait_for_a_completion(size_t c0) {
     std::unique_lock<std::mutex> lk(mu);
-    const size_t c0 = completions;
     n_waiting++;
     done_cv.wait_for(lk, std::chrono::seconds(60), [&] { return completions != c0; });
     n_waiting--;
@@ -165,9 +189,10 @@ struct bn254s_ctx : BufPool {
   // proofs - and the first wide arithmetic of a step started milliseconds late.  Repeating one batch (tools/step_overheads.py):
   // 74.4-75.1 -> 77.4-77.9 proofs/s for the order alone, 78.9-79.6 with three concurrent sections; bench.py, whose steps prove
   // fresh inputs and end on the slowest proof-of-work search of eight, measures no difference (76 either way).
-  // BN254S_BIG_CAP / BN254S_BIG_COST_NTT / BN254S_BIG_COST_EXCL / BN254S_BIG_COST_HASH / BN254S_SCHED_FIFO override (tuning only).
+  // BN254S_BIG_CAP / BN254S_BIG_COST_NTT / BN254S_BIG_COST_EXCL / BN254S_BIG_COST_HASH / BN254S_SCHED_FIFO override (tuning only; FIFO admission
+  // is the default, BN254S_SCHED_FIFO=0 switches it off).
   int big_cap = 9, big_cost[3] = {9, 3, 3}, big_used = 0;
-  bool big_fifo = false;
+  bool big_fifo = true;  // BN254S_SCHED_FIFO=0: the unordered semaphore (A/B runs)
   unsigned long big_ticket = 0, big_serving = 0;
   void big_lock(int cls) {
     std::unique_lock<std::mutex> lk(big_mu);
@@ -190,7 +215,22 @@ struct bn254s_ctx : BufPool {
     }
     big_cv.notify_all();
   }
+  // Slots are created on demand by the entry points (caller's thread) while workers of an earlier batch read slots[s]: the
+  // vector never reallocates (capacity reserved in the constructor, BN254S_SLOTS is clamped to MAX_SLOTS) and grows under slots_mu.
+  static constexpr size_t MAX_SLOTS = 64;
+  std::mutex slots_mu, err_mu;
+  bn254s_ctx() { slots.reserve(MAX_SLOTS); }
+  void set_err(const std::string& e) {
+    std::lock_guard<std::mutex> lk(err_mu);
+    err = e;
+  }
+  size_t n_slots_now() {
+    std::lock_guard<std::mutex> lk(slots_mu);
+    return slots.size();
+  }
   Slot* slot(size_t i) {
+    if (i >= MAX_SLOTS) return nullptr;
+    std::lock_guard<std::mutex> lk(slots_mu);
     while (slots.size() <= i) {
       Slot* s = new Slot();
       if (hipStreamCreateWithFlags(&s->st, hipStreamNonBlocking) != hipSuccess) {
@@ -207,7 +247,7 @@ struct bn254s_ctx : BufPool {
   do {                                                                                      \
     hipError_t e_ = (call);                                                                 \
     if (e_ != hipSuccess) {                                                                 \
-      (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                       \
+      (ctx)->set_err(std::string(#call) + ": " + hipGetErrorString(e_));                    \
       return BN254S_E_HIP;                                                                  \
     }                                                                                       \
   } while (0)

@@ -169,7 +169,7 @@ __global__ __launch_bounds__(64) void k_m2g_finish(const u64* __restrict__ o, co
   do {                                                            \
     hipError_t e_ = (call);                                       \
     if (e_ != hipSuccess) {                                       \
-      c->err = std::string(#call) + ": " + hipGetErrorString(e_); \
+      c->set_err(std::string(#call) + ": " + hipGetErrorString(e_)); \
       return BN254S_E_HIP;                                        \
     }                                                             \
   } while (0)
@@ -264,7 +264,7 @@ extern "C" int bn254s_map_to_g2(bn254s_ctx* c, const bn254s_params* params, cons
   MCHK(hipMemcpyAsync(&h_err, d_err, 4, hipMemcpyDeviceToHost, st));
   MCHK(hipStreamSynchronize(st));
   if (h_err) {
-    c->err = "map_to_g2: square root self-check failed";
+    c->set_err("map_to_g2: square root self-check failed");
     for (size_t i = 0; i < n_fq; i++) bn254s_proof_free(fq_proofs[i]);
     return h_err;
   }
@@ -301,7 +301,7 @@ extern "C" int bn254s_map_to_g2(bn254s_ctx* c, const bn254s_params* params, cons
     }
   }
   if (h_err) {
-    c->err = "map_to_g2: output equals +-offset";
+    c->set_err("map_to_g2: output equals +-offset");
     return h_err;
   }
   return BN254S_OK;

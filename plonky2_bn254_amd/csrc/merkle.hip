@@ -4,6 +4,7 @@
 // hash_or_noop(leaf) (leaves of <= 4 elements are not hashed), inner nodes = two_to_one, cap = the 2^cap_height
 // nodes at that depth.  One lane per leaf, sponge state in VGPRs, round constants read through the
 // scalar/constant path; leaves are read column-major so that consecutive lanes touch consecutive words.
+#include <algorithm>
 #include "merkle.h"
 #include "poseidon_dev.h"
 
@@ -16,7 +17,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
 #if defined(__HIP_DEVICE_COMPILE__)  // (the host pass only needs the signature)
   size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n_leaves) return;
-  const u32 lane_off = (u32)(j * leaf_stride);  // host side guarantees n_leaves * leaf_stride < 2^29
+  const u32 lane_off = (u32)(j * leaf_stride);  // n_leaves * leaf_stride <= 2^29 per launch (merkle_leaves cuts larger inputs)
   u64 s[4] = {0, 0, 0, 0};
   if (leaf_len <= 4) {
     for (int i = 0; i < leaf_len; i++) s[i] = data[(size_t)i * elem_stride + lane_off];
@@ -107,10 +108,18 @@ __global__ __launch_bounds__(256) void k_leaf_hash_coop(const u64* __restrict__ 
 void merkle_leaves(const u64* data, size_t leaf_stride, size_t elem_stride, int leaf_len, int log_leaves, u64* tree,
                    hipStream_t s) {
   size_t n = (size_t)1 << log_leaves;
-  if (leaf_len > 4 && n * (size_t)((leaf_len + 7) / 8) <= 4 * COOP_MAX_NODES)  // small trees (FRI layers): latency matters
+  if (leaf_len > 4 && n * (size_t)((leaf_len + 7) / 8) <= 4 * COOP_MAX_NODES) {  // small trees (FRI layers): latency matters
     k_leaf_hash_coop<<<(unsigned)((16 * n + 255) / 256), 256, 0, s>>>(data, leaf_stride, elem_stride, leaf_len, n, tree);
-  else
-    k_leaf_hash<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(data, leaf_stride, elem_stride, leaf_len, n, tree);
+    return;
+  }
+  // k_leaf_hash addresses a leaf with a 32-bit byte offset: a launch covers at most 2^29 words of leaf offsets (whole
+  // workgroups of 256 leaves); anything larger is cut into several launches over consecutive leaf ranges
+  size_t per_launch = n;
+  if (leaf_stride && n * leaf_stride > ((size_t)1 << 29)) per_launch = std::max((size_t)256, ((((size_t)1 << 29) / leaf_stride) / 256) * 256);
+  for (size_t j0 = 0; j0 < n; j0 += per_launch) {
+    const size_t cnt = std::min(per_launch, n - j0);
+    k_leaf_hash<<<(unsigned)((cnt + 255) / 256), 256, 0, s>>>(data + j0 * leaf_stride, leaf_stride, elem_stride, leaf_len, cnt, tree + 4 * j0);
+  }
 }
 
 void merkle_upper(int log_leaves, int cap_height, u64* tree, hipStream_t s) {

@@ -708,6 +708,7 @@ __global__ __launch_bounds__(256) void k_coset_unscale_half(u64* __restrict__ c,
   col[pos] = gl_mul(col[pos], gl_pow(base_inv, k1 + (k2 << log_r)));
 }
 
+void ntt_split_tables_free(NttSplitTables* S);
 int ntt_split_tables_init(NttSplitTables* S, unsigned log_n) {
   if (log_n < 18 || log_n > 23) return -1;  // e < 2^22 in split_pow
   S->log_n = log_n;
@@ -717,14 +718,17 @@ int ntt_split_tables_init(NttSplitTables* S, unsigned log_n) {
     if (hipMalloc((void**)dst, h.size() * 8) != hipSuccess) return -1;
     return hipMemcpy(*dst, h.data(), h.size() * 8, hipMemcpyHostToDevice) == hipSuccess ? 0 : -1;
   };
-  fill_pow_table(h, w, 2048);
-  if (upload(&S->fwd_lo)) return -1;
-  fill_pow_table(h, gl_pow(w, 2048), 2048);
-  if (upload(&S->fwd_hi)) return -1;
-  fill_pow_table(h, wi, 2048);
-  if (upload(&S->inv_lo)) return -1;
-  fill_pow_table(h, gl_pow(wi, 2048), 2048);
-  if (upload(&S->inv_hi)) return -1;
+  S->fwd_lo = S->fwd_hi = S->inv_lo = S->inv_hi = nullptr;
+  const u64 bases[4] = {w, gl_pow(w, 2048), wi, gl_pow(wi, 2048)};
+  u64** dsts[4] = {&S->fwd_lo, &S->fwd_hi, &S->inv_lo, &S->inv_hi};
+  for (int t = 0; t < 4; t++) {
+    fill_pow_table(h, bases[t], 2048);
+    if (upload(dsts[t])) {
+      ntt_split_tables_free(S);  // the tables uploaded so far (hipFree(nullptr) is a no-op)
+      S->fwd_lo = S->fwd_hi = S->inv_lo = S->inv_hi = nullptr;
+      return -1;
+    }
+  }
   const u64 w2N = gl_root_of_unity(log_n + 1);
   S->shift[0] = GL_GEN;
   S->shift[1] = gl_mul(GL_GEN, w2N);

@@ -160,8 +160,11 @@ static int get_point_tables(bn254s_ctx* c, unsigned log_n, QPointTables& pt) {
   return 0;
 }
 
+// `after_alloc` (optional) is called once the workspace of the proof is complete: the out-of-memory retry of the batch entry
+// points holds WorkPool::retry_mu up to that point, so that allocation attempts never interleave.
 static int prove_on_slot(bn254s_ctx* c, Slot& sl, int kind, const bn254s_params& P, const u64* scalars, const u64* x,
-                         const u64* off, size_t n, bn254s_proof* pr, std::string& err) {
+                         const u64* off, size_t n, bn254s_proof* pr, std::string& err,
+                         const std::function<void()>* after_alloc = nullptr) {
   const StarkShape sh = shape_for(kind);
   const int PW = point_words(kind);
   const size_t N = rows_for(n, P.min_rows_log2);
@@ -322,6 +325,7 @@ static int prove_on_slot(bn254s_ctx* c, Slot& sl, int kind, const bn254s_params&
     mem.release();  // a workspace that could not be completed is given back: the context stays usable for smaller proofs
     return BN254S_E_OOM;
   }
+  if (after_alloc) (*after_alloc)();
   int* d_err = (int*)(d_in + in_words);
   unsigned long long* d_pow = (unsigned long long*)(d_in + in_words + 2);
   u32* d_qidx = (u32*)(d_qout + wpq * P.num_queries);
@@ -727,25 +731,6 @@ static int prove_on_slot(bn254s_ctx* c, Slot& sl, int kind, const bn254s_params&
 // ---- C ABI ------------------------------------------------------------------------------------------------------
 extern "C" {
 
-int bn254s_prove_g1(bn254s_ctx* c, const bn254s_params* params, const uint64_t* scalars, const uint64_t* x,
-                    const uint64_t* off, size_t n, bn254s_proof** out) {
-  if (!c || !params || !scalars || !x || !off || !out || n == 0 || params->struct_size != sizeof(bn254s_params))
-    return BN254S_E_INVALID_ARG;
-  *out = nullptr;
-  HIP_TRY(c, hipSetDevice(c->device));
-  Slot* sl = c->slot(0);
-  if (!sl) return BN254S_E_HIP;
-  bn254s_proof* pr = new bn254s_proof();
-  int rc = prove_on_slot(c, *sl, KIND_G1, *params, scalars, x, off, n, pr, c->err);
-  if (rc != BN254S_OK) {
-    hipStreamSynchronize(sl->st);
-    delete pr;
-    return rc;
-  }
-  *out = pr;
-  return BN254S_OK;
-}
-
 // A batch in flight: proof i of the batch is one task of the context's worker pool (ctx.h WorkPool).
 struct bn254s_batch {
   bn254s_ctx* c = nullptr;
@@ -776,7 +761,7 @@ int bn254s_prove_batch_begin(bn254s_ctx* c, int kind, const bn254s_params* param
   // queue).  With batches queued back to back (bench.py: two steps open) 8 / 10 / 12 / 14 / 16 slots give 81.0 / 83.0 / 84.0-84.7 /
   // 85.0 / 84.3 proofs/s; one batch of eight proofs alone uses eight of them.
   size_t n_slots = 12;
-  if (const char* e = getenv("BN254S_SLOTS")) n_slots = std::max(1, atoi(e));
+  if (const char* e = getenv("BN254S_SLOTS")) n_slots = std::min((size_t)bn254s_ctx::MAX_SLOTS, (size_t)std::max(1, atoi(e)));
   for (size_t s = 0; s < n_slots; s++)
     if (!c->slot(s)) return BN254S_E_HIP;
   c->workers.start(n_slots, c->device);
@@ -803,24 +788,36 @@ int bn254s_prove_batch_begin(bn254s_ctx* c, int kind, const bn254s_params* param
         const size_t b = i * B->per_proof, cnt = std::min(B->per_proof, B->n_total - b);
         bn254s_proof* pr = new bn254s_proof();
         std::string err;
-        int rc = prove_on_slot(B->c, *B->c->slots[s], B->kind, B->params, B->scalars + 4 * b, B->x + PW * b,
-                               B->off ? B->off + PW * b : nullptr, cnt, pr, err);
+        bn254s_ctx* c = B->c;
+        Slot& sl = *c->slot(s);
+        auto attempt = [&](const std::function<void()>* after_alloc) {
+          err.clear();
+          return prove_on_slot(c, sl, B->kind, B->params, B->scalars + 4 * b, B->x + PW * b, B->off ? B->off + PW * b : nullptr, cnt,
+                               pr, err, after_alloc);
+        };
+        int rc = attempt(nullptr);
         // Out of device memory: the workspaces the idle slots keep from earlier (smaller or differently shaped) proofs may be
         // what is in the way - give those back and try again; while other proofs are still running, wait for one of them to
         // finish and repeat (a batch of tall proofs then runs as many at a time as fit).  Alone and still too large: the error.
+        // One task at a time does this (retry_mu, held until its workspace is complete or has been given back): two proofs
+        // that both fit alone never fail on each other's partial workspaces, and "nobody else is running" is decided under
+        // the same lock.  The completion counter is sampled before the attempt, so a proof that ends during it is not missed.
+        WorkPool& wp = c->workers;
         while (rc == BN254S_E_OOM) {
-          B->c->workers.for_idle_slots([&](size_t i) {
-            if (i < B->c->slots.size()) B->c->slots[i]->mem.release();
+          std::unique_lock<std::mutex> rl(wp.retry_mu);
+          const size_t c0 = wp.completions_now();
+          wp.for_idle_slots([&](size_t i) {
+            if (i < c->n_slots_now()) c->slot(i)->mem.release();
           });
-          const bool last = B->c->workers.active() <= 1;  // nobody else is running: nothing more will be given back
-          err.clear();
-          rc = prove_on_slot(B->c, *B->c->slots[s], B->kind, B->params, B->scalars + 4 * b, B->x + PW * b,
-                             B->off ? B->off + PW * b : nullptr, cnt, pr, err);
+          const bool last = wp.active() <= 1;  // nobody else is running: nothing more will be given back
+          const std::function<void()> unlock = [&]() { rl.unlock(); };
+          rc = attempt(&unlock);
+          if (rl.owns_lock()) rl.unlock();
           if (rc != BN254S_E_OOM || last) break;
-          B->c->workers.wait_for_a_completion();
+          wp.wait_for_a_completion(c0);
         }
         if (rc != BN254S_OK) {
-          hipStreamSynchronize(B->c->slots[s]->st);
+          hipStreamSynchronize(sl.st);
           delete pr;
           std::lock_guard<std::mutex> lk(B->mu);
           if (B->first_rc == 0) {
@@ -846,7 +843,7 @@ int bn254s_prove_batch_end(bn254s_batch* B) {
   }
   const int rc = B->first_rc;
   if (rc) {
-    B->c->err = B->err;
+    B->c->set_err(B->err);
     for (size_t i = 0; i < B->n_proofs; i++) {
       delete B->out[i];
       B->out[i] = nullptr;
@@ -868,23 +865,19 @@ int bn254s_prove_g1_batch(bn254s_ctx* c, const bn254s_params* params, const uint
   return bn254s_prove_batch(c, KIND_G1, params, scalars, x, off, n_total, per_proof, proofs_out);
 }
 
+// The single-proof entry points queue ONE proof of n instances on the worker pool, like a batch of one: a call made while a
+// batch is open (between bn254s_prove_batch_begin and _end) takes its turn behind the proofs already queued and runs on a free
+// slot - it never shares a stream or workspace with a running proof.
 static int prove_one(bn254s_ctx* c, int kind, const bn254s_params* params, const uint64_t* scalars, const uint64_t* x,
                      const uint64_t* off, size_t n, bn254s_proof** out) {
   if (!c || !params || !scalars || !x || (kind != KIND_FQ && !off) || !out || n == 0 || params->struct_size != sizeof(bn254s_params))
     return BN254S_E_INVALID_ARG;
   *out = nullptr;
-  HIP_TRY(c, hipSetDevice(c->device));
-  Slot* sl = c->slot(0);
-  if (!sl) return BN254S_E_HIP;
-  bn254s_proof* pr = new bn254s_proof();
-  int rc = prove_on_slot(c, *sl, kind, *params, scalars, x, off, n, pr, c->err);
-  if (rc != BN254S_OK) {
-    hipStreamSynchronize(sl->st);
-    delete pr;
-    return rc;
-  }
-  *out = pr;
-  return BN254S_OK;
+  return bn254s_prove_batch(c, kind, params, scalars, x, off, n, n, out);
+}
+int bn254s_prove_g1(bn254s_ctx* c, const bn254s_params* params, const uint64_t* scalars, const uint64_t* x, const uint64_t* off,
+                    size_t n, bn254s_proof** out) {
+  return prove_one(c, KIND_G1, params, scalars, x, off, n, out);
 }
 // One process, several GPUs: proof i goes to context i mod n_ctx (proofs share no state), each context
 // pipelines its share exactly like bn254s_prove_batch.  No inter-GPU traffic.
@@ -981,7 +974,7 @@ int bn254s_generate_trace(bn254s_ctx* c, int kind, const uint64_t* scalars, cons
                           uint32_t min_rows_log2, uint64_t* trace_out, uint64_t* outputs) {
   if (!c || kind < 0 || kind > 2 || !scalars || !x || (kind != KIND_FQ && !off) || n == 0 || !trace_out) return BN254S_E_INVALID_ARG;
   if (min_rows_log2 < 16) {  // the range-check table needs all 2^16 values (scalar_mul_stark.rs:71-87)
-    c->err = "min_rows_log2 must be >= 16";
+    c->set_err("min_rows_log2 must be >= 16");
     return BN254S_E_INVALID_ARG;
   }
   HIP_TRY(c, hipSetDevice(c->device));
@@ -1005,7 +998,7 @@ int bn254s_generate_trace(bn254s_ctx* c, int kind, const uint64_t* scalars, cons
             : kind == KIND_G2 ? g2_generate_trace_device(d_sc, d_x, d_off, n, d_trace, N, d_scr, d_out, d_err, c->stream)
                               : fq_generate_trace_device(d_sc, d_x, n, d_trace, N, d_scr, d_out, d_err, c->stream);
   if (trc) {
-    c->err = "trace generation launch failed";
+    c->set_err("trace generation launch failed");
     return BN254S_E_HIP;
   }
   int h_err = 0;
@@ -1014,7 +1007,7 @@ int bn254s_generate_trace(bn254s_ctx* c, int kind, const uint64_t* scalars, cons
   if (outputs) HIP_TRY(c, hipMemcpyAsync(outputs, d_out, n * (size_t)PW * 8, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   if (h_err) {
-    c->err = "trace generation reported device error " + std::to_string(h_err);
+    c->set_err("trace generation reported device error " + std::to_string(h_err));
     return h_err;
   }
   return BN254S_OK;

@@ -494,12 +494,12 @@ extern "C" int bn254s_verify(bn254s_ctx* c, int kind, const bn254s_params* param
       (kind != KIND_FQ && !off) || !outputs || n == 0 || degree_bits < 7 || degree_bits > 30)
     return BN254S_E_INVALID_ARG;
   if (params->num_challenges != 2 || params->rate_bits != 1) {
-    c->err = "only num_challenges = 2, rate_bits = 1 are supported";
+    c->set_err("only num_challenges = 2, rate_bits = 1 are supported");
     return BN254S_E_UNSUPPORTED;
   }
   if (hipSetDevice(c->device) != hipSuccess) return BN254S_E_HIP;
   std::string err;
   int rc = verify_impl(c, kind, *params, (int)degree_bits, words, n_words, scalars, x, off, outputs, n, err);
-  if (rc != BN254S_OK) c->err = err;
+  if (rc != BN254S_OK) c->set_err(err);
   return rc;
 }

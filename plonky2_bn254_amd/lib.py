@@ -45,6 +45,7 @@ def load_library():
     lib.bn254s_params_default.argtypes = [C.POINTER(Params)]
     lib.bn254s_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
     lib.bn254s_ctx_destroy.argtypes = [vp]
+    lib.bn254s_ctx_trim.argtypes = [vp]
     lib.bn254s_last_error.argtypes = [vp]
     lib.bn254s_last_error.restype = C.c_char_p
     for name in ("bn254s_prove_g1", "bn254s_prove_g2"):
@@ -115,28 +116,35 @@ class Proof:
 
     # the 1.1 MB of proof words are copied out of the library's buffer on first use (a throughput loop that only needs the caps
     # and the stage times does not pay for eight copies per step)
+    def _fetch(self, fn, what):
+        if not self._h:
+            raise RuntimeError(f"Proof.{what}: the proof was closed before its {what} were read")
+        data, n = U64P(), C.c_size_t()
+        rc = fn(self._h, C.byref(data), C.byref(n))
+        if rc != 0:
+            raise RuntimeError(f"bn254s_proof_{what} failed with {rc}")
+        return data, n.value
+
     @property
     def words(self) -> np.ndarray:
         if self._words is None:
-            data, n = U64P(), C.c_size_t()
-            self._lib.bn254s_proof_words(self._h, C.byref(data), C.byref(n))
-            self._words = np.ctypeslib.as_array(data, shape=(n.value,)).copy()
+            data, n = self._fetch(self._lib.bn254s_proof_words, "words")
+            self._words = np.ctypeslib.as_array(data, shape=(n,)).copy()
         return self._words
 
     @property
     def outputs(self) -> np.ndarray:
         if self._outputs is None:
-            data, n = U64P(), C.c_size_t()
-            self._lib.bn254s_proof_outputs(self._h, C.byref(data), C.byref(n))
-            self._outputs = np.ctypeslib.as_array(data, shape=(n.value,)).copy() if n.value else np.zeros(0, np.uint64)
+            data, n = self._fetch(self._lib.bn254s_proof_outputs, "outputs")
+            self._outputs = np.ctypeslib.as_array(data, shape=(n,)).copy() if n else np.zeros(0, np.uint64)
         return self._outputs
 
     def caps(self) -> np.ndarray:
         """The three Merkle caps (trace, auxiliary, quotient): the first 192 words of the proof."""
         if self._words is not None:
             return self._words[:192].copy()
-        data, n = U64P(), C.c_size_t()
-        self._lib.bn254s_proof_words(self._h, C.byref(data), C.byref(n))
+        data, n = self._fetch(self._lib.bn254s_proof_words, "words")
+        assert n >= 192
         return np.ctypeslib.as_array(data, shape=(192,)).copy()
 
     SECTIONS = ("trace_cap", "auxiliary_polys_cap", "quotient_polys_cap", "local_values", "next_values", "auxiliary_polys",
@@ -159,12 +167,18 @@ class Proof:
         return buf.raw
 
     def close(self):
+        """Frees the library's copy; `words` and `outputs` stay readable (they are copied out first)."""
         if self._h:
-            self._lib.bn254s_proof_free(self._h)
-            self._h = None
+            try:
+                self.words, self.outputs
+            finally:
+                self._lib.bn254s_proof_free(self._h)
+                self._h = None
 
     def __del__(self):
-        self.close()
+        if getattr(self, "_h", None):  # (no copy on garbage collection: nobody can read it afterwards)
+            self._lib.bn254s_proof_free(self._h)
+            self._h = None
 
 
 class Context:
@@ -187,6 +201,10 @@ class Context:
 
     def __del__(self):
         self.close()
+
+    def trim(self):
+        """bn254s_ctx_trim: idle slots give their (grow-only) workspaces back to the driver."""
+        self._check(self._lib.bn254s_ctx_trim(self._h), "bn254s_ctx_trim")
 
     def _check(self, rc, what):
         if rc != 0:

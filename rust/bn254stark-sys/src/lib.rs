@@ -69,11 +69,13 @@ extern "C" {
     pub fn bn254s_prove_batch(ctx: *mut Bn254sCtx, kind: c_int, params: *const Bn254sParams, scalars: *const u64,
                               x: *const u64, offset: *const u64, n_total: usize, per_proof: usize,
                               proofs: *mut *mut Bn254sProof) -> c_int;
-    /// one context per GPU, proof i on context i mod n_ctx
+    /// queues the batch on the context's worker pool and returns; `bn254s_prove_batch_end` waits for it.  Inputs and
+    /// `proofs_out` must outlive the handle.  Other proving calls made meanwhile queue behind it (never share a slot).
     pub fn bn254s_prove_batch_begin(ctx: *mut Bn254sCtx, kind: c_int, params: *const Bn254sParams, scalars: *const u64,
                                     x: *const u64, offset: *const u64, n_total: usize, per_proof: usize,
                                     proofs_out: *mut *mut Bn254sProof, handle: *mut *mut Bn254sBatch) -> c_int;
     pub fn bn254s_prove_batch_end(handle: *mut Bn254sBatch) -> c_int;
+    /// one context per GPU, proof i on context i mod n_ctx
     pub fn bn254s_prove_batch_multi(ctxs: *mut *mut Bn254sCtx, n_ctx: usize, kind: c_int, params: *const Bn254sParams,
                                     scalars: *const u64, x: *const u64, offset: *const u64, n_total: usize,
                                     per_proof: usize, proofs: *mut *mut Bn254sProof) -> c_int;

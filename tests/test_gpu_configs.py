@@ -7,7 +7,7 @@ import pytest
 
 import bench
 import plonky2_bn254_amd as pk
-from plonky2_bn254_amd import synth
+from tools import synth
 from tests import oracle_lib
 
 pytestmark = pytest.mark.gpu

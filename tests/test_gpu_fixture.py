@@ -38,3 +38,24 @@ def test_compare_fixture_pipeline(gpu_ctx, oracle, tmp_path, kind, n):
     log = []
     assert not cf.compare(gpu_ctx, kind, fin, fdump, out=log.append)
     assert any(ln.startswith("trace: DIFFERENT") and "[7]" in ln for ln in log)
+
+
+@pytest.mark.parametrize("kind", ["g1", "g2", "fq"])
+def test_gpu_proof_equals_committed_fixture_expectation(gpu_ctx, tmp_path, kind):
+    """tests/golden/fixture/<kind>_{inputs,expected}.txt are what a machine with cargo and no GPU diffs the reference's own dump
+    against (tools/diff_fixture.py, rust/README.md): the GPU prover must produce exactly those words and trace column digests."""
+    import os
+    from tools import diff_fixture as df
+    d = os.path.join(os.path.dirname(__file__), "golden", "fixture")
+    k = ex.KINDS[kind]
+    s, x, o = ex.read(os.path.join(d, kind + "_inputs.txt"), kind)
+    trace, _ = gpu_ctx.generate_trace(k, s, x, o)
+    pr = {0: gpu_ctx.prove_g1, 1: gpu_ctx.prove_g2}[k](s, x, o) if k != 2 else gpu_ctx.prove_fq_exp(s, x)
+    dump = str(tmp_path / "gpu_dump.txt")
+    cf.write_dump(dump, trace, pr.words)       # the format rust/shim/dump_fixture.rs writes
+    log = []
+    assert df.diff(os.path.join(d, kind + "_expected.txt"), dump, out=log.append), log
+    assert any(ln.startswith("pow_witness") and "(same)" in ln for ln in log), log
+    exp = df.parse_expected(os.path.join(d, kind + "_expected.txt"))
+    assert exp["sections"]["head"][1][:64] == [int(v) for v in pr.section("trace_cap")]
+    assert exp["sections"]["final_poly"][1] == [int(v) for v in pr.section("final_poly")]

@@ -4,7 +4,7 @@ restated native verifier."""
 import numpy as np
 import pytest
 
-from plonky2_bn254_amd import synth
+from tools import synth
 from tests import oracle_lib
 
 pytestmark = pytest.mark.gpu

@@ -8,7 +8,7 @@ import os
 import numpy as np
 import pytest
 
-from plonky2_bn254_amd import synth
+from tools import synth
 
 pytestmark = pytest.mark.gpu
 

@@ -8,7 +8,7 @@ verifier (src/starks/common/verifier.rs:32-98) and rejection of corrupted proofs
 import numpy as np
 import pytest
 
-from plonky2_bn254_amd import synth
+from tools import synth
 from tests import oracle_lib
 
 pytestmark = pytest.mark.gpu

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 import plonky2_bn254_amd as pk
-from plonky2_bn254_amd import synth
+from tools import synth
 from tests import oracle_lib
 
 pytestmark = pytest.mark.gpu
@@ -167,3 +167,37 @@ def test_batches_in_flight_match_the_blocking_call(gpu_ctx):
     good = hg.end()
     assert np.array_equal(good[0].words, ref_g1[0])
     assert np.array_equal(gpu_ctx.prove_g1(s[:128], x[:128], o[:128]).words, ref_g1[0])
+
+
+def test_single_proof_calls_while_a_batch_is_open(gpu_ctx):
+    """The threading rule of include/bn254_stark.h: between bn254s_prove_batch_begin and _end the context may be entered again;
+    bn254s_prove_g1 / _fq_exp / bn254s_verify called meanwhile give the right proof (they queue on the same worker pool and
+    never share a slot - stream, workspace, staging buffer - with a proof of the open batch), and the batch is unharmed."""
+    s, x, o = synth.g1_inputs(128 * 6, seed=53)
+    fs, fx = synth.fq_inputs(9, seed=54)
+    ref_batch = [p.words.copy() for p in gpu_ctx.prove_g1_batch(s, x, o)]
+    ref_single = gpu_ctx.prove_g1(s[:5], x[:5], o[:5]).words.copy()
+    ref_fq = gpu_ctx.prove_fq_exp(fs, fx).words.copy()
+    for rounds in range(2):
+        h = gpu_ctx.prove_batch_begin(0, s, x, o)           # six proofs running on slots 0..5
+        a = gpu_ctx.prove_g1(s[:5], x[:5], o[:5])           # a different shape (padded proof) in between
+        b = gpu_ctx.prove_fq_exp(fs, fx)                    # and a different kind
+        gpu_ctx.verify(0, a.words, 16, s[:5], x[:5], o[:5], a.outputs)
+        h2 = gpu_ctx.prove_batch_begin(0, s[:256], x[:256], o[:256])
+        c = gpu_ctx.prove_g1(s[128:256], x[128:256], o[128:256])
+        got, got2 = h.end(), h2.end()
+        assert np.array_equal(a.words, ref_single) and np.array_equal(b.words, ref_fq)
+        assert np.array_equal(c.words, ref_batch[1])
+        assert len(got) == 6 and all(np.array_equal(g.words, r) for g, r in zip(got, ref_batch))
+        assert all(np.array_equal(g.words, r) for g, r in zip(got2, ref_batch[:2]))
+
+
+def test_closed_proof_keeps_its_words(gpu_ctx):
+    s, x, o = synth.g1_inputs(2, seed=57)
+    p = gpu_ctx.prove_g1(s, x, o)
+    q = gpu_ctx.prove_g1(s, x, o)
+    w = p.words.copy()
+    q.close()                          # words / outputs are copied out before the library's copy is freed
+    assert np.array_equal(q.words, w) and q.outputs.size == 16 and np.array_equal(q.caps(), w[:192])
+    with pytest.raises(RuntimeError):
+        q.section("trace_cap")

@@ -3,7 +3,7 @@ calls: reference src/hook.rs:63-71, rows = (512 n).next_power_of_two(), scalar_m
 import numpy as np
 import pytest
 
-from plonky2_bn254_amd import synth
+from tools import synth
 from tests import oracle_lib
 
 pytestmark = pytest.mark.gpu

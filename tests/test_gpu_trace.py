@@ -2,7 +2,7 @@
 import numpy as np
 import pytest
 
-from plonky2_bn254_amd import synth
+from tools import synth
 from tests import oracle_lib
 
 pytestmark = pytest.mark.gpu

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 import plonky2_bn254_amd as pk
-from plonky2_bn254_amd import synth
+from tools import synth
 from tests import oracle_lib
 
 pytestmark = pytest.mark.gpu

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 import plonky2_bn254_amd as pk
-from plonky2_bn254_amd import synth
+from tools import synth
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 

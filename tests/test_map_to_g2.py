@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 from tools import map_to_g2_ref as m2g
-from plonky2_bn254_amd import synth
+from tools import synth
 
 
 def on_twist(pt):

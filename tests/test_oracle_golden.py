@@ -6,7 +6,7 @@ import os
 import numpy as np
 import pytest
 
-from plonky2_bn254_amd import synth
+from tools import synth
 from tests import oracle_lib
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
@@ -231,10 +231,53 @@ def test_oracle_reproduces_the_committed_proof_digest(oracle):
     import hashlib
     import json
     import os
-    from plonky2_bn254_amd import synth
+    from tools import synth
     from tests import oracle_lib
     g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "proof_digests.json")))["fq_exp"]
     s, x = synth.fq_inputs(g["n"], seed=g["seed"])
     proof, outs, _, degree_bits = oracle_lib.prove(oracle, 2, s, x)
     assert degree_bits == g["degree_bits"] and proof.size == g["n_words"]
     assert hashlib.sha256(np.ascontiguousarray(proof, dtype="<u8").tobytes()).hexdigest() == g["sha256_proof_words"]
+
+
+def test_committed_fork_fixture_is_what_the_oracle_proves_and_diff_tool_localises(oracle, tmp_path):
+    """tests/golden/fixture/fq_expected.txt (tools/gen_fixture_expected.py) re-derived by the oracle; tools/diff_fixture.py (the
+    pure-Python half of the fork cross-check, rust/README.md) accepts a dump in the Rust dumper's format, tolerates another
+    valid proof-of-work witness and localises a witness difference to the trace and a transcript difference to its proof word."""
+    import os
+    from tools import compare_fixture as cf
+    from tools import diff_fixture as df
+    from tools import export_fixture_inputs as ex
+    from tools import gen_fixture_expected as gen
+    d = os.path.join(os.path.dirname(__file__), "golden", "fixture")
+    s, x, o, text, trace, words = gen.make("fq", oracle)
+    assert text == open(os.path.join(d, "fq_expected.txt")).read()
+    s2, x2, _ = ex.read(os.path.join(d, "fq_inputs.txt"), "fq")
+    assert np.array_equal(s, s2) and np.array_equal(x, x2)
+    for kind in ("g1", "g2"):     # the other two kinds: inputs file = the synthetic inputs, expectation well-formed
+        si, xi, oi = ex.inputs(kind, gen.CASES[kind], gen.SEED)
+        sr, xr, orr = ex.read(os.path.join(d, kind + "_inputs.txt"), kind)
+        assert np.array_equal(si, sr) and np.array_equal(xi, xr) and np.array_equal(oi, orr)
+        e = df.parse_expected(os.path.join(d, kind + "_expected.txt"))
+        w, a = gen.WIDTH_AUX[kind]
+        assert e["ncols"] == w and e["nrows"] == 65536 and len(e["sections"]["head"][1]) == 192 + 4 * (w + a) + 12 + 192
+        assert e["sections"]["init_challenger_state"][0] == e["n_words"] - 12
+    dump = str(tmp_path / "dump.txt")
+    exp = os.path.join(d, "fq_expected.txt")
+    cf.write_dump(dump, trace, words)
+    assert df.diff(exp, dump, out=lambda *_: None)
+    other = words.copy()
+    other[-13] += np.uint64(12345)                  # another witness: legitimate (rayon find_any), still "identical where it must be"
+    cf.write_dump(dump, trace, other)
+    log = []
+    assert df.diff(exp, dump, out=log.append) and any("find_any" in ln for ln in log)
+    bad_t = trace.copy()
+    bad_t[5, 9] ^= np.uint64(1)
+    cf.write_dump(dump, bad_t, words)
+    log = []
+    assert not df.diff(exp, dump, out=log.append) and any("trace: DIFFERENT" in ln and "[5]" in ln for ln in log)
+    bad_w = words.copy()
+    bad_w[200] ^= np.uint64(1)                      # an opening
+    cf.write_dump(dump, trace, bad_w)
+    log = []
+    assert not df.diff(exp, dump, out=log.append) and any("head: DIFFERENT at proof word 200" in ln for ln in log)

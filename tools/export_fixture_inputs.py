@@ -3,7 +3,7 @@ usage: python tools/export_fixture_inputs.py [--kind g1|g2|fq] [n=128] [out=fixt
 import sys
 
 sys.path.insert(0, __file__.rsplit("/tools/", 1)[0])
-from plonky2_bn254_amd import synth
+from tools import synth
 
 KINDS = {"g1": 0, "g2": 1, "fq": 2}
 

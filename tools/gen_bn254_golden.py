@@ -7,7 +7,7 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from plonky2_bn254_amd import synth
+from tools import synth
 
 P = synth.P
 rng = synth.Xoshiro256ss(2024)

@@ -12,7 +12,7 @@ import sys
 import numpy as np
 
 sys.path.insert(0, __file__.rsplit("/tools/", 1)[0])
-from plonky2_bn254_amd import synth
+from tools import synth
 from tests import oracle_lib
 
 

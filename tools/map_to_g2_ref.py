@@ -20,8 +20,8 @@ from __future__ import annotations
 
 import numpy as np
 
-from plonky2_bn254_amd import synth
-from plonky2_bn254_amd.synth import P, f2_add, f2_inv, f2_mul, f2_sub
+from tools import synth
+from tools.synth import P, f2_add, f2_inv, f2_mul, f2_sub
 
 COFACTOR = 21888242871839275222246405745257275088844257914179612981679871602714643921549  # hash_to_g2.rs:69-71
 LEGENDRE_EXP = (P - 1) // 2

@@ -3,7 +3,7 @@ tools/proof_timeline.py to see the kernels of the LAST proof in order.  usage: p
 import sys
 sys.path.insert(0, __file__.rsplit("/tools/", 1)[0])
 import plonky2_bn254_amd as pk
-from plonky2_bn254_amd import synth
+from tools import synth
 
 kind = {"g1": 0, "g2": 1, "fq": 2}[sys.argv[1]]
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5

@@ -2,7 +2,7 @@ import sys, time
 sys.path.insert(0, __file__.rsplit('/tools/', 1)[0])
 import numpy as np
 import plonky2_bn254_amd as pk
-from plonky2_bn254_amd import synth
+from tools import synth
 ctx = pk.Context(0)
 s, x, o = synth.g1_inputs(128 * 8)
 for k in (8, 16, 32):

@@ -10,7 +10,7 @@ import numpy as np
 sys.path.insert(0, __file__.rsplit("/tools/", 1)[0])
 import plonky2_bn254_amd as pk
 from tools import map_to_g2_ref as m2g
-from plonky2_bn254_amd import synth
+from tools import synth
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 check = len(sys.argv) > 2 and sys.argv[2] == "1"

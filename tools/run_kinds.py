@@ -5,7 +5,7 @@ import time
 
 sys.path.insert(0, __file__.rsplit("/tools/", 1)[0])
 import plonky2_bn254_amd as pk
-from plonky2_bn254_amd import synth
+from tools import synth
 
 kinds = (sys.argv[1] if len(sys.argv) > 1 else "g1,g2,fq").split(",")
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 3

@@ -2,7 +2,7 @@
 import sys, time
 sys.path.insert(0, __file__.rsplit("/tools/", 1)[0])
 import plonky2_bn254_amd as pk
-from plonky2_bn254_amd import synth
+from tools import synth
 ctx = pk.Context(0)
 s, x, o = synth.g1_inputs(1024)
 ctx.prove_g1(s, x, o)

@@ -7,7 +7,7 @@ import time
 sys.path.insert(0, __file__.rsplit("/tools/", 1)[0])
 import numpy as np
 import plonky2_bn254_amd as pk
-from plonky2_bn254_amd import synth
+from tools import synth
 
 kind = sys.argv[1] if len(sys.argv) > 1 else "fq"
 log_rows = int(sys.argv[2]) if len(sys.argv) > 2 else 21

@@ -1,7 +1,7 @@
 import sys
 sys.path.insert(0, "/root/repo")
 import plonky2_bn254_amd as pk
-from plonky2_bn254_amd import synth
+from tools import synth
 ctx = pk.Context(0)
 for kind, name, ins in ((0, "g1", synth.g1_inputs(128)), (1, "g2", synth.g2_inputs(128)), (2, "fq", synth.fq_inputs(128))):
     off = ins[2] if len(ins) > 2 else None
