@@ -231,6 +231,9 @@ int bn254s_poseidon_permute(bn254s_ctx* ctx, uint64_t* states, size_t n);
 /* debug: the hand-written Goldilocks sequences of the NTT kernels (csrc/gl_asm.h) on n operand pairs; out[n][17] =
  * a+b, a-b, b-a, a*b, a*2^{12,24,32,36,48,60,64,1,31}, a*2^-{12,24,1,31} (all mod p) */
 int bn254s_selftest_field(bn254s_ctx* ctx, const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out);
+/* Debug: BN254 Fq inversion as trace generation uses it (ark-ff `inverse()` at add.rs:66,80): x[n][4] canonical little-endian
+ * words -> out[n][8] = x^-1 mod p twice, by the divstep inversion of the product path and by Fermat's little theorem. */
+int bn254s_selftest_fq_inv(bn254s_ctx* ctx, const uint64_t* x, size_t n, uint64_t* out);
 /* Trace generation only: column-major trace[W][rows] copied to the host buffer.
  * kind: 0 = G1 scalar mul (W 781), 1 = G2 scalar mul (W 1295), 2 = Fq exp (W 427; offset ignored). */
 int bn254s_generate_trace(bn254s_ctx* ctx, int kind, const uint64_t* scalars, const uint64_t* x, const uint64_t* offset,

@@ -12,6 +12,40 @@
 namespace orc {
 
 // In-place iterative DIT on base-field data; `root` must be a primitive N-th root of unity.
+// Twiddles: stage `len` uses w^(k n/len), k < len/2; they are laid out stage by stage (tw[half + k] for the stage of half-size
+// `half`: n - 1 words) so that the inner loop reads them contiguously, and kept per (n, root) for the life of the process -
+// a proof runs thousands of transforms of the same three sizes.
+struct TwiddleTable {
+  std::vector<u64> tw;  // tw[half + k] = root^(k n / (2 half)), half = 1, 2, 4, ..., n/2
+};
+static inline const TwiddleTable& twiddles_for(size_t n, u64 root) {
+  struct Entry {
+    size_t n;
+    u64 root;
+    TwiddleTable* t;
+  };
+  static std::vector<Entry> cache;
+  const TwiddleTable* hit = nullptr;
+#pragma omp critical(orc_twiddle_cache)
+  {
+    for (auto& e : cache)
+      if (e.n == n && e.root == root) hit = e.t;
+    if (!hit) {
+      TwiddleTable* t = new TwiddleTable();
+      t->tw.assign(n > 1 ? n : 2, 1);
+      std::vector<u64> pw(n / 2 ? n / 2 : 1);
+      pw[0] = 1;
+      for (size_t k = 1; k < n / 2; k++) pw[k] = gl_mul(pw[k - 1], root);
+      for (size_t half = 1; half < n; half <<= 1) {
+        const size_t step = n / (2 * half);
+        for (size_t k = 0; k < half; k++) t->tw[half + k] = pw[k * step];
+      }
+      cache.push_back({n, root, t});
+      hit = t;
+    }
+  }
+  return *hit;
+}
 template <class T>
 static void fft_inplace_root(std::vector<T>& a, u64 root) {
   size_t n = a.size();
@@ -20,16 +54,14 @@ static void fft_inplace_root(std::vector<T>& a, u64 root) {
     size_t j = reverse_bits(i, lg);
     if (i < j) std::swap(a[i], a[j]);
   }
-  // twiddle table w^k, k < n/2
-  std::vector<u64> tw(n / 2 ? n / 2 : 1);
-  tw[0] = 1;
-  for (size_t k = 1; k < n / 2; k++) tw[k] = gl_mul(tw[k - 1], root);
+  const u64* tw = twiddles_for(n, root).tw.data();
   for (size_t len = 2; len <= n; len <<= 1) {
-    size_t half = len / 2, step = n / len;
+    const size_t half = len / 2;
+    const u64* w = tw + half;
     for (size_t i = 0; i < n; i += len)
       for (size_t k = 0; k < half; k++) {
         T u = a[i + k];
-        T v = mul_base(a[i + k + half], tw[k * step]);
+        T v = mul_base(a[i + k + half], w[k]);
         a[i + k] = u + v;
         a[i + k + half] = u - v;
       }

@@ -58,6 +58,15 @@ void orc_set_num_threads(int n) {
 u64 orc_gl_mul(u64 a, u64 b) { return gl_mul(a, b); }
 u64 orc_gl_inv(u64 a) { return gl_inv(a); }
 void orc_poseidon_permute(u64* state12) { poseidon_permute(state12); }
+void orc_poseidon_permute_fast(u64* state12) { poseidon_permute_fast(state12); }
+void orc_set_fast_poseidon(int on) { g_fast_poseidon = on != 0; }
+// n chained permutations on one state (timing of a single core; tools/oracle_speed.py)
+void orc_permute_chain(u64* state12, size_t n, int fast) {
+  for (size_t i = 0; i < n; i++) {
+    if (fast) poseidon_permute_fast(state12);
+    else poseidon_permute(state12);
+  }
+}
 void orc_hash_or_noop(const u64* x, size_t n, u64* out4) {
   Digest d = hash_or_noop(x, n);
   memcpy(out4, d.e, 32);

@@ -305,14 +305,20 @@ static inline std::vector<std::vector<u64>> lookup_helper_columns(const StarkDef
   std::vector<u64> tbl(N);
   for (size_t i = 0; i < N; i++) tbl[i] = gl_add(challenge, trace[def.table_col][i]);
   std::vector<u64> tinv = gl_batch_inv(tbl);
+  // Z_(i+1) = Z_i + sum_k h_k(i) - freq(i) / (x + table(i)).  The row sums are formed column by column over blocks of rows
+  // (the helper columns are column-major: walking them row by row touches m cache lines per row), then one serial prefix sum.
+  std::vector<u64> rowsum(N, 0);
+  const size_t BLK = 2048;
+#pragma omp parallel for schedule(static)
+  for (size_t i0 = 0; i0 < N; i0 += BLK) {
+    const size_t i1 = i0 + BLK < N ? i0 + BLK : N;
+    for (int k = 0; k < m; k++)
+      for (size_t i = i0; i < i1; i++) rowsum[i] = gl_add(rowsum[i], out[k][i]);
+    for (size_t i = i0; i < i1; i++) rowsum[i] = gl_sub(rowsum[i], gl_mul(trace[def.freq_col][i], tinv[i]));
+  }
   std::vector<u64>& z = out[m];
   z[0] = 0;
-  for (size_t i = 0; i + 1 < N; i++) {
-    u64 x = 0;
-    for (int k = 0; k < m; k++) x = gl_add(x, out[k][i]);
-    x = gl_sub(x, gl_mul(trace[def.freq_col][i], tinv[i]));
-    z[i + 1] = gl_add(z[i], x);
-  }
+  for (size_t i = 0; i + 1 < N; i++) z[i + 1] = gl_add(z[i], rowsum[i]);
   return out;
 }
 
@@ -666,7 +672,7 @@ static inline Proof prove(const StarkDef& def, const StarkConfig& cfg, const std
         u64 s2[12];
         memcpy(s2, st, sizeof(s2));
         s2[pos] = c;
-        poseidon_permute(s2);
+        poseidon_hash_permute(s2);
         if ((s2[7] >> (64 - cfg.pow_bits)) == 0) {  // >= pow_bits leading zeros
 #pragma omp critical
           if (c < found) found = c;

@@ -2,6 +2,7 @@
 // The proving entry points live in prover.hip.
 #include "ctx.h"
 #include "merkle.h"
+#include "trace_g1.h"
 #include "poseidon_dev.h"
 
 // one per translation unit: loads its code object (defined at the end of each .hip file)
@@ -265,6 +266,22 @@ int bn254s_selftest_field(bn254s_ctx* c, const uint64_t* a, const uint64_t* b, s
   field_selftest(d, d + n, d + 2 * n, n, c->stream);
   HIP_TRY(c, hipGetLastError());
   HIP_TRY(c, hipMemcpyAsync(out, d + 2 * n, 8 * FIELD_SELFTEST_OUTS * n, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return BN254S_OK;
+}
+
+// Debug: BN254 Fq inversion on the device, x[n][4] canonical words -> out[n][8] = x^-1 by divsteps (the product's fq_inv) and by
+// Fermat's little theorem (0 -> 0).
+int bn254s_selftest_fq_inv(bn254s_ctx* c, const uint64_t* x, size_t n, uint64_t* out) {
+  if (!c || !x || !out) return BN254S_E_INVALID_ARG;
+  if (n == 0) return BN254S_OK;
+  HIP_TRY(c, hipSetDevice(c->device));
+  u64* d = c->words("fi.io", 12 * n);
+  if (!d) return BN254S_E_OOM;
+  HIP_TRY(c, hipMemcpyAsync(d, x, 32 * n, hipMemcpyHostToDevice, c->stream));
+  launch_fq_inv_selftest(d, d + 4 * n, n, c->stream);
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipMemcpyAsync(out, d + 4 * n, 64 * n, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   return BN254S_OK;
 }

@@ -283,14 +283,166 @@ __device__ __forceinline__ fqw fq_to_canonical(const fq& a) {
   return fq_pack(fq_mul(a, one));
 }
 
-// a^(p-2); a != 0.  Not inlined: used once per batch-inversion thread.
-__device__ __noinline__ fq fq_inv(const fq& a) {
+// a^(p-2); a != 0 (Fermat: 254 squarings + 127 products, ~125 k instructions).  Kept for A/B runs (BN254S_FQ_INV_FERMAT at
+// compile time) and as the definition fq_inv is tested against.
+__device__ __noinline__ fq fq_inv_fermat(const fq& a) {
   fq r = fq_one();
   for (int i = 253; i >= 0; i--) {  // p-2 < 2^254
     r = fq_sqr(r);
     if ((FQ_PM2[i >> 6] >> (i & 63)) & 1) r = fq_mul(r, a);
   }
   return r;
+}
+
+// ---- inversion by divsteps (Bernstein-Yang "safegcd") -----------------------------------------------------------------
+// f = p, g = x; a divstep is (delta, f, g) -> (1 - delta, g, (g - f)/2) if delta > 0 and g odd, else (1 + delta, f, (g + (g odd) f)/2);
+// 586 of them bring any g < 2^254 to 0 and f to +-1 (the published bound for this variant: floor((45907 b + 26313)/19929),
+// b = 254), and d, e follow along with (d, e) = x^-1 (f, g) mod p, so d = +-x^-1 at the end.  Twenty rounds of thirty divsteps:
+// a round works on the low 30 bits of f and g only (32-bit registers) and yields a 2 x 2 integer matrix (u v; q r) with
+// 2^30 (f', g') = (u v; q r)(f, g); the matrix is then applied to the full values - nine signed 30-bit limbs, 64-bit
+// column sums from v_mad_i64_i32, no carry chain through VCC - and to (d, e) modulo p (a multiple of p makes the low 30 bits
+// vanish before the shift).  ~12 k instructions per inversion against ~125 k of the Fermat form; branch-free, so the
+// lanes of a wave stay together.  zeta = -(delta + 1/2) as a 32-bit integer.
+static constexpr int FQ30_N = 9;
+static constexpr int FQ30_MASK = (1 << 30) - 1;
+__device__ static constexpr int FQ30_P[FQ30_N] = {0x187cfd47, 0x3082305b, 0x71ca8d3, 0x205aa45a, 0x1585d97, 0x116da06, 0x1a029b85, 0x139cb84c, 0x3064};
+static constexpr u32 FQ30_PINV = 0x1b799c77;  // p^-1 mod 2^30
+// R^3 mod p (R = 2^260) in 26-bit limbs: (x R)^-1 R^3 R^-1 = x^-1 R
+__device__ static constexpr u32 FQ_R3[FQ_NL] = {0x3e3a1a8, 0xc91e0f, 0x16c513e, 0x25dab49, 0x2c59c28, 0x180fe5c, 0x3872393, 0x21fd714, 0x1ed8d19, 0x43c5b};
+
+struct fq30 {
+  int v[FQ30_N];
+};
+__device__ __forceinline__ void fq30_divsteps(int& zeta, u32 f, u32 g, int& u, int& v, int& q, int& r) {
+  u32 uu = 1, vv = 0, qq = 0, rr = 1;
+  int z = zeta;
+#pragma unroll
+  for (int i = 0; i < 30; i++) {
+    u32 c1 = (u32)(z >> 31);          // delta > 0
+    const u32 c2 = 0u - (g & 1u);     // g odd
+    const u32 x = (f ^ c1) - c1, y = (uu ^ c1) - c1, w = (vv ^ c1) - c1;  // (f, u, v) negated when delta > 0
+    g += x & c2;
+    qq += y & c2;
+    rr += w & c2;
+    c1 &= c2;                          // swap
+    z = (int)(((u32)z ^ c1) - 1u);
+    f += g & c1;
+    uu += qq & c1;
+    vv += rr & c1;
+    g >>= 1;
+    uu <<= 1;
+    vv <<= 1;
+  }
+  zeta = z;
+  u = (int)uu;
+  v = (int)vv;
+  q = (int)qq;
+  r = (int)rr;
+}
+// (f, g) <- (u f + v g, q f + r g) / 2^30 (exact)
+__device__ __forceinline__ void fq30_update_fg(fq30& f, fq30& g, int u, int v, int q, int r) {
+  long long cf = (long long)u * f.v[0] + (long long)v * g.v[0];
+  long long cg = (long long)q * f.v[0] + (long long)r * g.v[0];
+  cf >>= 30;
+  cg >>= 30;
+#pragma unroll
+  for (int i = 1; i < FQ30_N; i++) {
+    cf += (long long)u * f.v[i] + (long long)v * g.v[i];
+    cg += (long long)q * f.v[i] + (long long)r * g.v[i];
+    f.v[i - 1] = (int)cf & FQ30_MASK;
+    g.v[i - 1] = (int)cg & FQ30_MASK;
+    cf >>= 30;
+    cg >>= 30;
+  }
+  f.v[FQ30_N - 1] = (int)cf;
+  g.v[FQ30_N - 1] = (int)cg;
+}
+// (d, e) <- (u d + v e, q d + r e) / 2^30 mod p, values kept in (-2p, p)
+__device__ __forceinline__ void fq30_update_de(fq30& d, fq30& e, int u, int v, int q, int r) {
+  const int sd = d.v[FQ30_N - 1] >> 31, se = e.v[FQ30_N - 1] >> 31;
+  int md = (u & sd) + (v & se), me = (q & sd) + (r & se);  // + p times these: brings negative d, e back up
+  long long cd = (long long)u * d.v[0] + (long long)v * e.v[0];
+  long long ce = (long long)q * d.v[0] + (long long)r * e.v[0];
+  md -= (int)((FQ30_PINV * (u32)cd + (u32)md) & (u32)FQ30_MASK);  // makes the low 30 bits of cd + p md vanish
+  me -= (int)((FQ30_PINV * (u32)ce + (u32)me) & (u32)FQ30_MASK);
+  cd += (long long)FQ30_P[0] * md;
+  ce += (long long)FQ30_P[0] * me;
+  cd >>= 30;
+  ce >>= 30;
+#pragma unroll
+  for (int i = 1; i < FQ30_N; i++) {
+    cd += (long long)u * d.v[i] + (long long)v * e.v[i] + (long long)FQ30_P[i] * md;
+    ce += (long long)q * d.v[i] + (long long)r * e.v[i] + (long long)FQ30_P[i] * me;
+    d.v[i - 1] = (int)cd & FQ30_MASK;
+    e.v[i - 1] = (int)ce & FQ30_MASK;
+    cd >>= 30;
+    ce >>= 30;
+  }
+  d.v[FQ30_N - 1] = (int)cd;
+  e.v[FQ30_N - 1] = (int)ce;
+}
+// d in (-2p, p), negated when sign < 0 -> [0, p)
+__device__ __forceinline__ void fq30_normalize(fq30& d, int sign) {
+  int add = d.v[FQ30_N - 1] >> 31;
+  const int neg = sign >> 31;
+  int c = 0;
+#pragma unroll
+  for (int i = 0; i < FQ30_N; i++) {
+    int x = d.v[i] + (FQ30_P[i] & add);
+    x = (x ^ neg) - neg;
+    c += x;
+    d.v[i] = i < FQ30_N - 1 ? c & FQ30_MASK : c;
+    if (i < FQ30_N - 1) c >>= 30;
+  }
+  add = d.v[FQ30_N - 1] >> 31;
+  c = 0;
+#pragma unroll
+  for (int i = 0; i < FQ30_N; i++) {
+    c += d.v[i] + (FQ30_P[i] & add);
+    d.v[i] = i < FQ30_N - 1 ? c & FQ30_MASK : c;
+    if (i < FQ30_N - 1) c >>= 30;
+  }
+}
+// a^-1 for a Montgomery residue a != 0 (0 -> 0).  Inlined: its body is a rolled loop of twenty rounds (~600 instructions), and a
+// call would force the caller's live field elements through scratch memory (k_fq_batch_inv kept 688 B per lane there).
+__device__ __forceinline__ fq fq_inv(const fq& a) {
+#if defined(BN254S_FQ_INV_FERMAT)
+  return fq_inv_fermat(a);
+#else
+  const fqw w = fq_pack(a);  // the residue as a plain integer below p
+  fq30 f, g, d, e;
+#pragma unroll
+  for (int i = 0; i < FQ30_N; i++) {
+    const int bit = 30 * i, k = bit >> 6, sh = bit & 63;
+    u64 x = w.l[k] >> sh;
+    if (sh + 30 > 64 && k + 1 < 4) x |= w.l[k + 1] << (64 - sh);
+    g.v[i] = (int)((u32)x & (u32)FQ30_MASK);
+    f.v[i] = FQ30_P[i];
+    d.v[i] = 0;
+    e.v[i] = i == 0 ? 1 : 0;
+  }
+  int zeta = -1;
+#pragma unroll 1
+  for (int it = 0; it < 20; it++) {
+    int u, v, q, r;
+    fq30_divsteps(zeta, (u32)f.v[0], (u32)g.v[0], u, v, q, r);
+    fq30_update_de(d, e, u, v, q, r);
+    fq30_update_fg(f, g, u, v, q, r);
+  }
+  fq30_normalize(d, f.v[FQ30_N - 1]);  // f = +-1: d = +-(a R)^-1
+  // nine 30-bit limbs -> ten 26-bit limbs, then times R^3 (Montgomery): (a R)^-1 R^3 R^-1 = a^-1 R
+  u64 ww[5] = {0, 0, 0, 0, 0};
+#pragma unroll
+  for (int i = 0; i < FQ30_N; i++) {
+    const int bit = 30 * i, k = bit >> 6, sh = bit & 63;
+    ww[k] |= (u64)(u32)d.v[i] << sh;
+    if (sh + 30 > 64) ww[k + 1] |= (u64)(u32)d.v[i] >> (64 - sh);
+  }
+  fq r3;
+#pragma unroll
+  for (int i = 0; i < FQ_NL; i++) r3.l[i] = FQ_R3[i];
+  return fq_mul(fq_unpack(ww), r3);
+#endif
 }
 
 // ---- G1 (y^2 = x^3 + 3), Jacobian coordinates -----------------------------------------------------------

@@ -18,44 +18,55 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
   size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n_leaves) return;
   const u32 lane_off = (u32)(j * leaf_stride);  // n_leaves * leaf_stride <= 2^29 per launch (merkle_leaves cuts larger inputs)
-  u64 s[4] = {0, 0, 0, 0};
-  if (leaf_len <= 4) {
-    for (int i = 0; i < leaf_len; i++) s[i] = data[(size_t)i * elem_stride + lane_off];
-  } else {
+  // leaf_len > 4: hash_no_pad (leaves of <= 4 elements are not hashed: k_leaf_copy below)
 #if defined(BN254S_POSEIDON_PLAIN)
-    u64 t[12];
+  u64 t[12];
 #pragma unroll
-    for (int i = 0; i < 12; i++) t[i] = 0;
+  for (int i = 0; i < 12; i++) t[i] = 0;
 #pragma unroll 1
-    for (int c = 0; c < leaf_len; c += 8) {
-      const u64* col = data + (size_t)c * elem_stride;
+  for (int c = 0; c < leaf_len; c += 8) {
+    const u64* col = data + (size_t)c * elem_stride;
 #pragma unroll
-      for (int i = 0; i < 8; i++)
-        if (c + i < leaf_len) t[i] = (col + (size_t)i * elem_stride)[lane_off];
-      poseidon_permute_plain(t);
-    }
-#pragma unroll
-    for (int i = 0; i < 4; i++) s[i] = t[i];
-#else
-    // the input of every permutation is parked here for the (rare) exact repeat: [lane of the state][thread], 96 B per thread
-    __shared__ u64 parked[12][256];
-    const u32 lds_addr = (u32)(uintptr_t)(__attribute__((address_space(3))) u64*)&parked[0][threadIdx.x];
-    const u32 byte_off = lane_off * 8u;
-    const u64 stride_bytes = (u64)elem_stride * 8u;
-    asm volatile(POSEIDON_ASM_SPONGE
-                 : [o0] "=&v"(s[0]), [o1] "=&v"(s[1]), [o2] "=&v"(s[2]), [o3] "=&v"(s[3])
-                 : [col] "s"(data), [off] "v"(byte_off), [stride] "s"(stride_bytes), [len] "s"(leaf_len),
-                   [rc] "s"(POSEIDON_RC_DEV), [tab] "s"(POSEIDON_INIT_DEV), [blk] "s"(POSEIDON_BLK_DEV),
-                   [lds] "v"(lds_addr)
-                 : POSEIDON_ASM_CLOBBERS, POSEIDON_ASM_SPONGE_CLOBBERS, "memory");
-#pragma unroll
-    for (int i = 0; i < 4; i++) s[i] = s[i] >= GL_P ? s[i] - GL_P : s[i];
-#endif
+    for (int i = 0; i < 8; i++)
+      if (c + i < leaf_len) t[i] = (col + (size_t)i * elem_stride)[lane_off];
+    poseidon_permute_plain(t);
   }
+  ulonglong2* o = reinterpret_cast<ulonglong2*>(digests + 4 * j);
+  o[0] = make_ulonglong2(t[0], t[1]);
+  o[1] = make_ulonglong2(t[2], t[3]);
+#else
+  // the input of every permutation is parked here for the (rare) exact repeat: [lane of the state][thread], 96 B per thread
+  __shared__ u64 parked[12][256];
+  const u32 lds_addr = (u32)(uintptr_t)(__attribute__((address_space(3))) u64*)&parked[0][threadIdx.x];
+  const u32 byte_off = lane_off * 8u;
+  const u64 stride_bytes = (u64)elem_stride * 8u;
+  const u32 digest_off = (u32)j * 32u;  // n_leaves <= 2^27 per launch
+  // The statement canonicalises the digest and stores it itself: it owns v10..v126, and with the digest coming back in four
+  // 64-bit outputs beside its inputs the compiler ran out of its ten registers and spilled to scratch memory (round 2: 24 B per
+  // lane, off the hot loop, but a private segment for every wave).
+  asm volatile(POSEIDON_ASM_SPONGE_STORE
+               :
+               : [col] "s"(data), [off] "v"(byte_off), [stride] "s"(stride_bytes), [len] "s"(leaf_len),
+                 [rc] "s"(POSEIDON_RC_DEV), [tab] "s"(POSEIDON_INIT_DEV), [blk] "s"(POSEIDON_BLK_DEV),
+                 [lds] "v"(lds_addr), [dig] "s"(digests), [doff] "v"(digest_off)
+               : POSEIDON_ASM_CLOBBERS, POSEIDON_ASM_SPONGE_CLOBBERS, "memory");
+#endif
+#endif
+}
+
+// hash_or_noop for leaves of at most four elements (the quotient commitment: 4 chunk polynomials): the digest is the leaf itself,
+// zero-padded.  Same addressing as k_leaf_hash.
+__global__ __launch_bounds__(256) void k_leaf_copy(const u64* __restrict__ data, size_t leaf_stride, size_t elem_stride, int leaf_len,
+                                                   size_t n_leaves, u64* __restrict__ digests) {
+  const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n_leaves) return;
+  u64 s[4] = {0, 0, 0, 0};
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+    if (i < leaf_len) s[i] = data[(size_t)i * elem_stride + j * leaf_stride];
   ulonglong2* o = reinterpret_cast<ulonglong2*>(digests + 4 * j);
   o[0] = make_ulonglong2(s[0], s[1]);
   o[1] = make_ulonglong2(s[2], s[3]);
-#endif
 }
 
 __global__ __launch_bounds__(256) void k_merkle_level(const u64* __restrict__ in, u64* __restrict__ out, size_t n_out) {
@@ -108,14 +119,18 @@ __global__ __launch_bounds__(256) void k_leaf_hash_coop(const u64* __restrict__ 
 void merkle_leaves(const u64* data, size_t leaf_stride, size_t elem_stride, int leaf_len, int log_leaves, u64* tree,
                    hipStream_t s) {
   size_t n = (size_t)1 << log_leaves;
-  if (leaf_len > 4 && n * (size_t)((leaf_len + 7) / 8) <= 4 * COOP_MAX_NODES) {  // small trees (FRI layers): latency matters
+  if (leaf_len <= 4) {
+    k_leaf_copy<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(data, leaf_stride, elem_stride, leaf_len, n, tree);
+    return;
+  }
+  if (n * (size_t)((leaf_len + 7) / 8) <= 4 * COOP_MAX_NODES) {  // small trees (FRI layers): latency matters
     k_leaf_hash_coop<<<(unsigned)((16 * n + 255) / 256), 256, 0, s>>>(data, leaf_stride, elem_stride, leaf_len, n, tree);
     return;
   }
   // k_leaf_hash addresses a leaf with a 32-bit byte offset: a launch covers at most 2^29 words of leaf offsets (whole
   // workgroups of 256 leaves); anything larger is cut into several launches over consecutive leaf ranges
-  size_t per_launch = n;
-  if (leaf_stride && n * leaf_stride > ((size_t)1 << 29)) per_launch = std::max((size_t)256, ((((size_t)1 << 29) / leaf_stride) / 256) * 256);
+  size_t per_launch = std::min(n, (size_t)1 << 27);  // (32-bit byte offsets of the digests, too)
+  if (leaf_stride && per_launch * leaf_stride > ((size_t)1 << 29)) per_launch = std::max((size_t)256, ((((size_t)1 << 29) / leaf_stride) / 256) * 256);
   for (size_t j0 = 0; j0 < n; j0 += per_launch) {
     const size_t cnt = std::min(per_launch, n - j0);
     k_leaf_hash<<<(unsigned)((cnt + 255) / 256), 256, 0, s>>>(data + j0 * leaf_stride, leaf_stride, elem_stride, leaf_len, cnt, tree + 4 * j0);

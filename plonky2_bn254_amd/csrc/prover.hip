@@ -325,6 +325,20 @@ static int prove_on_slot(bn254s_ctx* c, Slot& sl, int kind, const bn254s_params&
     mem.release();  // a workspace that could not be completed is given back: the context stays usable for smaller proofs
     return BN254S_E_OOM;
   }
+  {
+    // The HIP runtime allocates device memory of its own while kernels run (scratch for the kernels that spill, per hardware
+    // queue; signals, kernel arguments): when that fails the queue aborts the whole process (HSA_STATUS_ERROR_OUT_OF_RESOURCES).
+    // A workspace that leaves less than the reserve free is therefore given back and reported as out of memory, which the batch
+    // entry points turn into "wait for a running proof to finish".  BN254S_MEM_RESERVE_MB overrides (default 6144).
+    static const size_t reserve = (size_t)(getenv("BN254S_MEM_RESERVE_MB") ? atol(getenv("BN254S_MEM_RESERVE_MB")) : 6144) << 20;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b < reserve) {
+      err = "device memory: " + std::to_string(free_b >> 20) + " MB would be left free, below the reserve of " +
+            std::to_string(reserve >> 20) + " MB kept for the runtime's own allocations";
+      mem.release();
+      return BN254S_E_OOM;
+    }
+  }
   if (after_alloc) (*after_alloc)();
   int* d_err = (int*)(d_in + in_words);
   unsigned long long* d_pow = (unsigned long long*)(d_in + in_words + 2);

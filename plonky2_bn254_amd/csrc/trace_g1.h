@@ -27,3 +27,4 @@ int g1_generate_trace_device(const u64* d_scalars, const u64* d_x, const u64* d_
 // counter column (defined in trace_g1.hip; hist = 65536 u32 of scratch)
 void launch_range_columns(u64* trace, size_t N, int rc_begin, int rc_end, int freq_col, int range_col, u32* hist, int* err,
                           hipStream_t st);
+void launch_fq_inv_selftest(const u64* in, u64* out, size_t n, hipStream_t st);

@@ -19,8 +19,29 @@
 #include "chain_coop.h"
 #include "trace_g1.h"
 
+#ifndef BN254S_BATCH_INV_CH
+#define BN254S_BATCH_INV_CH 4
+#endif
 // ---- batched field inversion ------------------------------------------------------------------------------
 // out[e] = in[e]^-1 (0 -> 0); each thread owns CH elements strided by the grid size.
+// (The backward pass is unrolled by template recursion: the unroller refuses a body of two inlined products "as too large" even
+// under a pragma, and a rolled loop would index v[] / pre[] dynamically, i.e. keep them in scratch memory.)
+template <int J, int CH>
+__device__ __forceinline__ void batch_inv_back(const fq (&v)[CH], const fq (&pre)[CH], fq& inv, u64* __restrict__ out, size_t count,
+                                               size_t tid, size_t T) {
+  if constexpr (J >= 0) {
+    const size_t e = tid + J * T;
+    if (e < count) {
+      if (fq_is_zero(v[J])) {
+        st_fq(out, count, e, fq_zero());
+      } else {
+        st_fq(out, count, e, fq_mul(inv, pre[J]));
+        if constexpr (J > 0) inv = fq_mul(inv, v[J]);
+      }
+    }
+    batch_inv_back<J - 1, CH>(v, pre, inv, out, count, tid, T);
+  }
+}
 template <int CH>
 __global__ __launch_bounds__(64) void k_fq_batch_inv(const u64* __restrict__ in, u64* __restrict__ out, size_t count) {
   LATENCY_KERNEL_PRIO();
@@ -35,18 +56,7 @@ __global__ __launch_bounds__(64) void k_fq_batch_inv(const u64* __restrict__ in,
     if (!fq_is_zero(v[j])) acc = fq_mul(acc, v[j]);
   }
   fq inv = fq_inv(acc);
-#pragma unroll
-  for (int j = CH - 1; j >= 0; j--) {
-    size_t e = tid + j * T;
-    if (e < count) {
-      if (fq_is_zero(v[j])) {
-        st_fq(out, count, e, fq_zero());
-      } else {
-        st_fq(out, count, e, fq_mul(inv, pre[j]));
-        inv = fq_mul(inv, v[j]);
-      }
-    }
-  }
+  batch_inv_back<CH - 1, CH>(v, pre, inv, out, count, tid, T);
 }
 
 // Goldilocks inverses of counter and counter-511 for counter in [0,512): computed once per context.
@@ -110,8 +120,27 @@ __global__ __launch_bounds__(256) void k_range_columns(u64* __restrict__ trace, 
 }
 
 
+// Debug / parity: out[i] = in[i]^-1 mod p on canonical words (0 -> 0), one lane per element, by divsteps (fq_inv) and by Fermat
+// (fq_inv_fermat): out[n][8] = the two results.
+__global__ __launch_bounds__(64) void k_fq_inv_selftest(const u64* __restrict__ in, u64* __restrict__ out, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const fq a = fq_from_canonical(in + 4 * i);
+  const bool z = fq_is_zero(a);
+  const fqw r0 = fq_to_canonical(z ? a : fq_inv(a)), r1 = fq_to_canonical(z ? a : fq_inv_fermat(a));
+  for (int k = 0; k < 4; k++) {
+    out[8 * i + k] = r0.l[k];
+    out[8 * i + 4 + k] = r1.l[k];
+  }
+}
+void launch_fq_inv_selftest(const u64* in, u64* out, size_t n, hipStream_t st) {
+  k_fq_inv_selftest<<<(unsigned)((n + 63) / 64), 64, 0, st>>>(in, out, n);
+}
+
 void launch_fq_batch_inv(const u64* in, u64* out, size_t count, hipStream_t st) {
-  const int CH = 8;
+  // one divstep inversion (~12 k instructions) per CH elements plus three products (~1 k) per element: CH = 4 keeps the arrays in
+  // registers (no scratch) and puts 4x as many waves on the GPU as the CH = 8 of the Fermat days
+  const int CH = BN254S_BATCH_INV_CH;
   size_t threads = (count + CH - 1) / CH;
   k_fq_batch_inv<CH><<<(unsigned)((threads + 63) / 64), 64, 0, st>>>(in, out, count);
 }

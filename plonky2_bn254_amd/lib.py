@@ -79,6 +79,7 @@ def load_library():
     lib.bn254s_bench_ntt.argtypes = [vp, C.c_size_t, C.c_int, C.POINTER(C.c_float)]
     lib.bn254s_poseidon_permute.argtypes = [vp, vp, C.c_size_t]
     lib.bn254s_selftest_field.argtypes = [vp, vp, vp, C.c_size_t, vp]
+    lib.bn254s_selftest_fq_inv.argtypes = [vp, vp, C.c_size_t, vp]
     lib.bn254s_bench_copy.argtypes = [vp, C.c_size_t, C.c_int]
     lib.bn254s_bench_leafhash.argtypes = [vp, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_float)]
     lib.bn254s_g1_generate_trace.argtypes = [vp, vp, vp, vp, C.c_size_t, C.c_uint32, vp, vp]
@@ -327,6 +328,13 @@ class Context:
         b = np.ascontiguousarray(b, dtype=np.uint64)
         out = np.zeros((a.shape[0], 17), np.uint64)
         self._check(self._lib.bn254s_selftest_field(self._h, _ptr(a), _ptr(b), a.shape[0], _ptr(out)), "bn254s_selftest_field")
+        return out
+
+    def selftest_fq_inv(self, x: np.ndarray) -> np.ndarray:
+        """Debug: x[n][4] canonical words -> out[n][8] = x^-1 mod p by divsteps and by Fermat (bn254s_selftest_fq_inv)."""
+        x = np.ascontiguousarray(x, dtype=np.uint64)
+        out = np.zeros((x.shape[0], 8), np.uint64)
+        self._check(self._lib.bn254s_selftest_fq_inv(self._h, _ptr(x), x.shape[0], _ptr(out)), "bn254s_selftest_fq_inv")
         return out
 
     def poseidon_permute(self, states: np.ndarray) -> np.ndarray:

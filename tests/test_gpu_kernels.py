@@ -103,3 +103,24 @@ def test_field_asm_edge_cases(gpu_ctx):
               [x * pow(2, 192 - k, P) % P for k in shr]
         got = [int(v) for v in out[i]]
         assert got == exp, (hex(x), hex(y), [j for j in range(17) if got[j] != exp[j]])
+
+
+def test_fq_inversion_by_divsteps(gpu_ctx):
+    """fq_inv (csrc/fq_dev.h: Bernstein-Yang divsteps in 30-bit signed limbs, 20 rounds of 30) against Python's pow(x, -1, p) and
+    against the Fermat form on the device: edge values (1, 2, p-1, p-2, (p+1)/2, powers of two, values with long runs of ones
+    or zeros in the low limbs, which drive the divstep matrices to their extremes), 0 -> 0, and random elements."""
+    from tools import synth
+    P = synth.P
+    import random
+    rng = random.Random(2024)
+    xs = [0, 1, 2, 3, P - 1, P - 2, (P + 1) // 2, (P - 1) // 2, 1 << 253, (1 << 253) + 1, (1 << 200) - 1, (1 << 254) % P,
+          (1 << 30) - 1, 1 << 30, (1 << 60) + 1, P - (1 << 30), P >> 1, 0x5555555555555555555555555555555555555555555555555555555555555555 % P,
+          0x3333333333333333333333333333333333333333333333333333333333333333 % P]
+    xs += [(1 << k) % P for k in range(1, 254, 7)] + [P - ((1 << k) % P) for k in range(1, 254, 11)]
+    xs += [rng.randrange(1, P) for _ in range(4000)] + [rng.randrange(1, 1 << 64) for _ in range(200)]
+    arr = np.array([[(x >> (64 * i)) & synth.MASK64 for i in range(4)] for x in xs], dtype=np.uint64)
+    out = gpu_ctx.selftest_fq_inv(arr)
+    for x, row in zip(xs, out):
+        got = synth.words_to_int(row[:4])
+        want = pow(x, -1, P) if x else 0
+        assert got == want and synth.words_to_int(row[4:]) == want, hex(x)

@@ -555,7 +555,7 @@ def build_permute():
     return p
 
 
-def build_sponge():
+def build_sponge(store=False):
     """hash_no_pad over leaf_len elements (leaf_len > 0) from the all-zero state: per chunk of <= 8 elements overwrite lanes
     0.., add round 0's constants (lazily: any representative), permute.  The loads of chunk c + 1 are issued before the
     permutation of chunk c into staging registers; the input of every permutation is parked in LDS for the (rare) exact
@@ -607,7 +607,7 @@ def build_sponge():
     MODE["fast"] = True
     p.emit("label", "next")
     p.emit("chunk_loop", "chunk")          # idx += 8; if (idx < len) goto chunk
-    p.emit("digest_out")
+    p.emit("digest_store" if store else "digest_out")
     return p
 
 
@@ -738,7 +738,7 @@ def run(ins, mem, state, leaf=None, stats=None):
         elif op == "zero_in":
             for i in range(12):
                 m.wr(vp(A[i][0]), 0)
-        elif op == "digest_out":
+        elif op in ("digest_out", "digest_store"):
             break
         elif op == "sponge_init":
             m.s[SB_LOOP + 4], m.s[SB_LOOP + 5] = 0, len(leaf)
@@ -889,6 +889,23 @@ def text(ins):
         elif op == "digest_out":
             for i in range(4):
                 L.append("v_mov_b64 %%[o%d], v[%d:%d]" % (i, A[i][0], A[i][1]))
+        elif op == "digest_store":
+            # canonical digest (a >= p: a - p = a + 2^32 - 1 mod 2^64) -> 32 bytes at dig + doff; the staging registers are free now
+            assert all(A[i][1] == A[i][0] + 1 and A[i + 1][0] == A[i][0] + 2 for i in range(3))
+            L.append("s_mov_b64 s[%d:%d], 0xffffffff" % (SB_CARRY, SB_CARRY + 1))
+            L.append("s_mov_b32 s%d, 0" % (SB_CARRY + 2))
+            L.append("s_mov_b32 s%d, -1" % (SB_CARRY + 3))          # s[+2:+3] = p - 1
+            for i in range(4):
+                tl = LD0 + 2 * i
+                L.append("v_lshl_add_u64 v[%d:%d], v[%d:%d], 0, s[%d:%d]" % (tl, tl + 1, A[i][0], A[i][1], SB_CARRY, SB_CARRY + 1))
+            for i in range(4):
+                tl = LD0 + 2 * i
+                L.append("v_cmp_lt_u64 vcc, s[%d:%d], v[%d:%d]" % (SB_CARRY + 2, SB_CARRY + 3, A[i][0], A[i][1]))
+                L.append("s_nop 1")
+                L.append("v_cndmask_b32 v%d, v%d, v%d, vcc" % (A[i][0], A[i][0], tl))
+                L.append("v_cndmask_b32 v%d, v%d, v%d, vcc" % (A[i][1], A[i][1], tl + 1))
+            L.append("global_store_dwordx4 %%[doff], v[%d:%d], %%[dig]" % (A[0][0], A[1][1]))
+            L.append("global_store_dwordx4 %%[doff], v[%d:%d], %%[dig] offset:16" % (A[2][0], A[3][1]))
         elif op == "s_rem":       # remaining = len - idx; element idx + k exists iff remaining > k
             L.append("s_sub_u32 s%d, s%d, s%d" % (S_CNT, SB_LOOP + 5, SB_LOOP + 4))
         elif op == "gload":
@@ -1026,8 +1043,10 @@ def main():
         return
     perm = pad_hazards(build_permute().ins)
     sponge = pad_hazards(build_sponge().ins)
+    sponge_store = pad_hazards(build_sponge(store=True).ins)
     assert_targets_safe(perm)
     assert_targets_safe(sponge)
+    assert_targets_safe(sponge_store)
 
     # ---- check: interpreter vs the textbook permutation ----
     def check(state):
@@ -1052,6 +1071,8 @@ def main():
     for n in (1, 5, 8, 9, 16, 21):
         leaf = [rnd.randrange(P) if rnd.random() < 0.7 else rnd.choice([0, P - 1, 1]) for _ in range(n)]
         got, bad, _ = run(sponge, mem, None, leaf, stats={"force": n % 2})
+        got2, _, _ = run(sponge_store, mem, None, leaf, stats={"force": n % 2})
+        assert got2 == got
         st = [0] * 12
         for c in range(0, n, 8):
             st[:len(leaf[c:c + 8])] = leaf[c:c + 8]
@@ -1079,6 +1100,10 @@ def main():
         f.write("#define POSEIDON_ASM_VGPR_FIRST %d\n#define POSEIDON_ASM_VGPR_LAST %d\n" % (VB, V_END - 1))
         write_macro(f, "POSEIDON_ASM_PERMUTE", text(perm))
         write_macro(f, "POSEIDON_ASM_SPONGE", text(sponge))
+        f.write("// POSEIDON_ASM_SPONGE_STORE: the same, but the CANONICAL digest is written to memory by the statement itself (32 bytes at\n"
+                "//   dig + doff: dig = scalar base address, doff = the lane's byte offset, 32 bits) instead of coming back in o0..o3: the\n"
+                "//   statement leaves the compiler ten VGPRs, and four 64-bit outputs beside its inputs made it spill to scratch memory.\n")
+        write_macro(f, "POSEIDON_ASM_SPONGE_STORE", text(sponge_store))
         f.write("#define POSEIDON_ASM_SPONGE_CLOBBERS " + ", ".join('"v%d"' % i for i in range(LD0, LD0 + 16)) + "\n")
         clob = ['"s%d"' % S_BLK, '"s%d"' % (S_BLK + 1)] + ['"v%d"' % i for i in range(VB, V_END)] + ['"s%d"' % i for i in list(range(SB_LOOP, SB_LOOP + 6)) + list(range(SB_CARRY, S_HALF + 1)) + [30, 31, 34, 35, 22, 23]] + ['"vcc"', '"scc"']
         f.write("#define POSEIDON_ASM_CLOBBERS " + ", ".join(clob) + "\n")
