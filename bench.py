@@ -166,7 +166,7 @@ def run_g1(args, pk, torch, synth, ctx, rank, world, dist, device, gather_device
     n_steps = args.warmup + args.steps
     inputs = [step_inputs(pool, i, rank) for i in range(n_steps)]
 
-    # A step = one batch (bn254s_prove_batch_begin ... _end + the cap gather).  Up to `--steps-in-flight` (default 2) steps are
+    # A step = one batch (bn254s_prove_batch_begin ... _end + the cap gather).  Up to `--steps-in-flight` (default: 32 proofs' worth) steps are
     # open at a time: the next batch is queued before the current one is collected, so its first proofs fill the GPU while the
     # last proofs of the current batch run their latency-bound tail (FRI folds, proof of work).  All K steps complete inside the
     # timed region; --steps-in-flight 1 is the strictly sequential loop (reported beside the headline as `sequential_steps`).
@@ -202,7 +202,15 @@ def run_g1(args, pk, torch, synth, ctx, rank, world, dist, device, gather_device
             dist.barrier()
         torch.cuda.synchronize()
 
-    depth = max(1, args.steps_in_flight)
+    depth = args.steps_in_flight if args.steps_in_flight > 0 else max(1, 32 // ppg)
+    # Set-up, not a step: every slot (stream + ~4 GB workspace of a proof in flight, allocated on first use) that the pipeline will
+    # touch is used once - `depth` batches in flight, as in the timed region.  Without it the W warm-up steps of a short run reach
+    # only the first slots and the remaining workspaces would be allocated (hipMalloc of gigabytes) inside the timed region.
+    prime = [step_inputs(pool, 100000 + i, rank) for i in range(depth)]
+    hs = [ctx.prove_batch_begin(0, s, x, o, per_proof=INSTANCES_PER_PROOF) for s, x, o in prime]
+    for h in hs:
+        h.end()
+    del hs, prime
     if args.warmup:
         run_steps(0, args.warmup, depth)
     sync()
@@ -264,8 +272,32 @@ def run_g1(args, pk, torch, synth, ctx, rank, world, dist, device, gather_device
     ntt_ms = stage_ms.get("trace_ntt", 0.0) + stage_ms.get("aux_ntt", 0.0)
     ntt_bytes = NTT_BYTES_PER_COL * (W + A)
     achieved = ntt_bytes / (ntt_ms * 1e-3) / 1e9 if ntt_ms > 0 else 0.0
-    excl_ms = ctx.bench_ntt(W + A, 20)      # the same stage alone on the GPU (no other stream), after the timed region
+    # the same stage alone on the GPU (no other stream), after the timed region, with the shader clock it holds (one probe wave
+    # samples the core-clock counter against the 100 MHz counter) ...
+    excl_ms, ntt_mhz, ntt_mhz_min = ctx.bench_ntt_clock(W + A, 20)
     excl = ntt_bytes / (excl_ms * 1e-3) / 1e9
+    # ... and the limit that actually binds it: vector-instruction issue.  floor = waves per SIMD x executed VALU instructions per
+    # wave (SQ_INSTS_VALU / SQ_WAVES of the committed PMC pass: static) x the issue cost of one half-rate instruction, measured
+    # live in cycles (bn254s_bench_issue: ns per instruction x its own clock) and converted at the clock the NTT stage holds.
+    valu_floor = None
+    try:
+        ntt_prof, ntt_prof_src = latest_profile("r*_ntt_valu.json")
+        issue_ns, issue_mhz = ctx.bench_issue()
+        if ntt_prof and ntt_mhz > 0 and issue_mhz > 0:
+            cyc = issue_ns * 1e-9 * issue_mhz * 1e6
+            n_simd = torch.cuda.get_device_properties(device).multi_processor_count * 4
+            waves_per_simd = (W + A) * N_ROWS / 16 / 64 / n_simd          # a lane owns 16 elements of a column
+            floor_ms = waves_per_simd * float(ntt_prof["valu_insts_per_wave_stage"]) * cyc / (ntt_mhz * 1e6) * 1e3
+            valu_floor = {"floor_ms": round(floor_ms, 4), "frac": round(floor_ms / ntt_ms, 4) if ntt_ms > 0 else None,
+                          "frac_exclusive": round(floor_ms / excl_ms, 4),
+                          "valu_insts_per_wave_stage": ntt_prof["valu_insts_per_wave_stage"], "valu_insts_source": f"static: {ntt_prof_src}",
+                          "waves_per_simd": round(waves_per_simd, 2), "cycles_per_valu_inst": round(cyc, 3),
+                          "issue_probe": {"ns_per_inst": round(issue_ns, 4), "mhz": round(issue_mhz, 1)},
+                          "ntt_stage_clock_mhz": {"mean": round(ntt_mhz, 1), "slowest_10us": round(ntt_mhz_min, 1)},
+                          "note": "the stage is bound by vector-instruction issue, not by HBM: frac = this floor / the measured "
+                                  "stage time (1.0 = every issue slot of every SIMD used by the stage's own instructions)"}
+    except Exception as e:
+        valu_floor = {"error": str(e)}
     pmc, pmc_src = latest_profile("r*_pmc_ntt.json")
     traffic = int(pmc["ntt_stage_traffic_bytes_per_1237_cols"]) if pmc else None
     # integer-ALU roofline of the Poseidon leaf hash (the kernel that bounds proofs/s): wave-level VALU instructions per
@@ -275,15 +307,22 @@ def run_g1(args, pk, torch, synth, ctx, rank, world, dist, device, gather_device
     try:
         lh_ms = ctx.bench_leafhash(W, 17, 5)
         prof, prof_src = latest_profile("r*_alu.json")
+        issue_ns2, issue_mhz2 = ctx.bench_issue()
         if prof:
             insts = float(prof["leaf_hash_valu_wave_insts_per_launch_781x2e17"])
-            peak = float(prof["valu_peak_wave_insts_per_s"])
-            ach = insts / (lh_ms * 1e-3)
+            # issue peak of the half-rate class measured live (bn254s_bench_issue, 8 waves per SIMD); the full-rate instructions of
+            # the permutation (v_mov_b32, v_sub_u32, v_min_u32: 16 % of it) cost about half an issue slot each
+            n_simd = torch.cuda.get_device_properties(device).multi_processor_count * 4
+            peak = n_simd / (issue_ns2 * 1e-9)
+            full_share = float(prof.get("full_rate_share", 0.158))
+            ach = insts * (1.0 - 0.46 * full_share) / (lh_ms * 1e-3)
             alu = {"bound": "valu-issue", "kernel": "k_leaf_hash (781 columns x 2^17 leaves = 12.8 M Poseidon permutations)",
-                   "achieved": round(ach / 1e9, 2), "peak": round(peak / 1e9, 2), "unit": "G wave-instr/s",
+                   "achieved": round(ach / 1e9, 2), "peak": round(peak / 1e9, 2), "unit": "G half-rate wave-instr/s",
                    "frac": round(ach / peak, 4), "ms": round(lh_ms, 4),
                    "valu_insts_per_permutation": prof.get("valu_insts_per_permutation"),
-                   "permutations_per_s": round((1 << 17) * 98 / (lh_ms * 1e-3) / 1e9, 3), "source": prof_src}
+                   "valu_insts_source": f"static: SQ_INSTS_VALU pass, {prof_src}; a full-rate instruction counted as 0.54 issue slots",
+                   "issue_probe": {"ns_per_inst": round(issue_ns2, 4), "mhz": round(issue_mhz2, 1)},
+                   "permutations_per_s": round((1 << 17) * 98 / (lh_ms * 1e-3) / 1e9, 3)}
         else:
             alu = {"ms": round(lh_ms, 4), "permutations_per_s": round((1 << 17) * 98 / (lh_ms * 1e-3) / 1e9, 3)}
     except Exception as e:
@@ -337,7 +376,8 @@ def run_g1(args, pk, torch, synth, ctx, rank, world, dist, device, gather_device
                      "algorithmic_bytes": ntt_bytes, "ms": round(ntt_ms, 4),
                      "exclusive": {"achieved": round(excl, 1), "frac": round(excl / HBM_PEAK_GBS, 4),
                                    "ms": round(excl_ms, 4),
-                                   "note": "same launches with no other stream on the GPU (bn254s_bench_ntt)"}},
+                                   "note": "same launches with no other stream on the GPU (bn254s_bench_ntt)"},
+                     "valu_floor": valu_floor},
         "roofline_alu": alu,
     }
     if world == 1 and not args.no_extras:
@@ -443,8 +483,9 @@ def main():
                     help="g1 = the headline metric (configs[1] / configs[3]); map_to_g2 = configs[4]")
     ap.add_argument("--proofs-per-gpu", type=int, default=0, help="override the per-GPU batch of the g1 workload")
     ap.add_argument("--inputs", type=int, default=MAP_TO_G2_INPUTS, help="map_to_g2 workload: total Fq2 inputs per step")
-    ap.add_argument("--steps-in-flight", type=int, default=2,
-                    help="batches open at a time (2: the next step is queued before the current one is collected; 1: sequential)")
+    ap.add_argument("--steps-in-flight", type=int, default=0,
+                    help="batches open at a time (k: step i + k is queued before step i is collected; 1: sequential; default: as "
+                         "many as keep 32 proofs queued = the library's slots: 4 steps of 8 proofs on one GPU, 2 steps of 16 on several)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the G2 / Fq-exp / tall-proof figures reported beside the headline")
     args = ap.parse_args()

@@ -213,6 +213,8 @@ int bn254s_map_to_g2(bn254s_ctx* ctx, const bn254s_params* params, const uint64_
 /* hash_to_fq2 (src/utils/hash_to_g2.rs:76-87): Poseidon challenger over `len` Goldilocks elements -> u in Fq2 (8 words), the
  * input of bn254s_map_to_g2; together they are the reference's hash_to_g2.  Host only, no context. */
 int bn254s_hash_to_fq2(const uint64_t* input, size_t len, uint64_t* out /* 8 */);
+/* n inputs of `len` elements each at once, on the device (inputs[n][len] -> out[n][8]); same values as n calls of the above. */
+int bn254s_hash_to_fq2_batch(bn254s_ctx* ctx, const uint64_t* inputs, size_t n, size_t len, uint64_t* out);
 
 /* ---- kernel-level entry points (parity tests and bench.py's roofline leg) ------------------------------ */
 /* PolynomialBatch::from_values on host column-major values[C][2^16]: outputs (any may be NULL)
@@ -222,6 +224,12 @@ int bn254s_commit_values(bn254s_ctx* ctx, const uint64_t* values, size_t ncols, 
 /* Times `iters` runs of the NTT/LDE stage (iNTT + both coset NTTs) on ncols resident columns of 2^16
  * synthetic values; returns average milliseconds per run through *ms (HIP events on the kernels' stream). */
 int bn254s_bench_ntt(bn254s_ctx* ctx, size_t ncols, int iters, float* ms);
+/* The same, and the shader clock (MHz) the GPU held while the stage ran: mean over the timed iterations and the slowest ~10 us
+ * interval (one extra wave samples the core-clock counter against the constant 100 MHz counter). */
+int bn254s_bench_ntt_clock(bn254s_ctx* ctx, size_t ncols, int iters, float* ms, float* mhz, float* mhz_min);
+/* Issue cost of the half-rate vector instruction class (64-bit adds / shifts / compares, v_mad_u64_u32, carry instructions) with
+ * eight waves per SIMD: nanoseconds per wave-instruction and SIMD, and the shader clock held during the measurement. */
+int bn254s_bench_issue(bn254s_ctx* ctx, float* ns_per_issue, float* mhz);
 /* PMC calibration: `iters` plain copies of `words` u64 with 8-byte-per-lane loads/stores (known traffic). */
 int bn254s_bench_copy(bn254s_ctx* ctx, size_t words, int iters);
 /* Times the Merkle leaf-hash kernel alone: ncols columns x 2^log_leaves rows of synthetic data, ms per run. */

@@ -1,5 +1,6 @@
 // C ABI of libbn254stark.so (include/bn254_stark.h): context management and kernel-level entry points.
 // The proving entry points live in prover.hip.
+#include <algorithm>
 #include "ctx.h"
 #include "merkle.h"
 #include "trace_g1.h"
@@ -185,6 +186,139 @@ int bn254s_bench_ntt(bn254s_ctx* c, size_t ncols, int iters, float* ms) {
   hipEventDestroy(e0);
   hipEventDestroy(e1);
   HIP_TRY(c, hipGetLastError());
+  return BN254S_OK;
+}
+
+// Shader clock while a stage runs: ONE wave samples the core-clock counter (s_memtime) against the constant 100 MHz counter
+// (s_memrealtime) every ~10 us until `stop` is set by the measured stream (or max_samples are taken: the loop is bounded).
+__global__ __launch_bounds__(64) void k_clock_probe(unsigned long long* __restrict__ samples, const int* __restrict__ stop, int max_samples,
+                                                    int* __restrict__ n_taken) {
+  if (threadIdx.x != 0) return;
+  int i = 0;
+  for (; i < max_samples; i++) {
+    samples[2 * i] = __builtin_readcyclecounter();
+    samples[2 * i + 1] = __builtin_amdgcn_s_memrealtime();
+    if (__hip_atomic_load(stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+      i++;
+      break;
+    }
+    __builtin_amdgcn_s_sleep(127);
+    __builtin_amdgcn_s_sleep(127);
+    __builtin_amdgcn_s_sleep(127);
+  }
+  *n_taken = i;
+}
+// Issue cost of the half-rate vector instructions the NTT and Poseidon kernels are made of (v_lshl_add_u64 here; v_mad_u64_u32,
+// 64-bit shifts / compares, carry instructions cost the same: tools/ubench/sgpr_ops.hip): 8 waves per SIMD, 4 independent
+// chains per wave, 2048 x 32 instructions per wave.
+__global__ __launch_bounds__(256) void k_issue_probe(u64* out) {
+  for (int i = 0; i < 2048; i++) {
+    asm volatile(
+        "v_lshl_add_u64 v[40:41], v[40:41], 0, v[48:49]\n v_lshl_add_u64 v[42:43], v[42:43], 0, v[48:49]\n"
+        "v_lshl_add_u64 v[44:45], v[44:45], 0, v[48:49]\n v_lshl_add_u64 v[46:47], v[46:47], 0, v[48:49]\n"
+        "v_lshl_add_u64 v[40:41], v[40:41], 0, v[48:49]\n v_lshl_add_u64 v[42:43], v[42:43], 0, v[48:49]\n"
+        "v_lshl_add_u64 v[44:45], v[44:45], 0, v[48:49]\n v_lshl_add_u64 v[46:47], v[46:47], 0, v[48:49]\n"
+        "v_lshl_add_u64 v[40:41], v[40:41], 0, v[48:49]\n v_lshl_add_u64 v[42:43], v[42:43], 0, v[48:49]\n"
+        "v_lshl_add_u64 v[44:45], v[44:45], 0, v[48:49]\n v_lshl_add_u64 v[46:47], v[46:47], 0, v[48:49]\n"
+        "v_lshl_add_u64 v[40:41], v[40:41], 0, v[48:49]\n v_lshl_add_u64 v[42:43], v[42:43], 0, v[48:49]\n"
+        "v_lshl_add_u64 v[44:45], v[44:45], 0, v[48:49]\n v_lshl_add_u64 v[46:47], v[46:47], 0, v[48:49]\n"
+        "v_lshl_add_u64 v[40:41], v[40:41], 0, v[48:49]\n v_lshl_add_u64 v[42:43], v[42:43], 0, v[48:49]\n"
+        "v_lshl_add_u64 v[44:45], v[44:45], 0, v[48:49]\n v_lshl_add_u64 v[46:47], v[46:47], 0, v[48:49]\n"
+        "v_lshl_add_u64 v[40:41], v[40:41], 0, v[48:49]\n v_lshl_add_u64 v[42:43], v[42:43], 0, v[48:49]\n"
+        "v_lshl_add_u64 v[44:45], v[44:45], 0, v[48:49]\n v_lshl_add_u64 v[46:47], v[46:47], 0, v[48:49]\n"
+        "v_lshl_add_u64 v[40:41], v[40:41], 0, v[48:49]\n v_lshl_add_u64 v[42:43], v[42:43], 0, v[48:49]\n"
+        "v_lshl_add_u64 v[44:45], v[44:45], 0, v[48:49]\n v_lshl_add_u64 v[46:47], v[46:47], 0, v[48:49]\n"
+        "v_lshl_add_u64 v[40:41], v[40:41], 0, v[48:49]\n v_lshl_add_u64 v[42:43], v[42:43], 0, v[48:49]\n"
+        "v_lshl_add_u64 v[44:45], v[44:45], 0, v[48:49]\n v_lshl_add_u64 v[46:47], v[46:47], 0, v[48:49]\n" ::
+            : "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47");
+  }
+  u32 a;
+  asm volatile("v_mov_b32 %0, v40" : "=v"(a));
+  out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = a;
+}
+// ns per wave-instruction and SIMD of the half-rate class with 8 waves per SIMD, and the shader clock held meanwhile.
+int bn254s_bench_issue(bn254s_ctx* c, float* ns_per_issue, float* mhz) {
+  if (!c || !ns_per_issue || !mhz) return BN254S_E_INVALID_ARG;
+  HIP_TRY(c, hipSetDevice(c->device));
+  hipDeviceProp_t prop;
+  HIP_TRY(c, hipGetDeviceProperties(&prop, c->device));
+  const int simds = prop.multiProcessorCount * 4, blocks = simds * 8 / 4;  // 256-thread blocks = 4 waves; 8 waves per SIMD
+  const int MAXS = 20000;
+  u64* d_out = c->words("iss.out", (size_t)blocks * 256);
+  unsigned long long* d_s = (unsigned long long*)c->words("clk.samples", 2 * (size_t)MAXS + 2);
+  if (!d_out || !d_s) return BN254S_E_OOM;
+  int* d_flags = (int*)(d_s + 2 * (size_t)MAXS);
+  hipStream_t ps = nullptr;
+  HIP_TRY(c, hipStreamCreateWithFlags(&ps, hipStreamNonBlocking));
+  HIP_TRY(c, hipMemsetAsync(d_flags, 0, 8, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  hipEvent_t e0, e1;
+  HIP_TRY(c, hipEventCreate(&e0));
+  HIP_TRY(c, hipEventCreate(&e1));
+  k_clock_probe<<<1, 64, 0, ps>>>(d_s, d_flags, MAXS, d_flags + 1);
+  const int reps = 12;
+  for (int i = 0; i < 4; i++) k_issue_probe<<<blocks, 256, 0, c->stream>>>(d_out);  // clock ramp
+  HIP_TRY(c, hipEventRecord(e0, c->stream));
+  for (int i = 0; i < reps; i++) k_issue_probe<<<blocks, 256, 0, c->stream>>>(d_out);
+  HIP_TRY(c, hipEventRecord(e1, c->stream));
+  (void)hipMemsetAsync(d_flags, 1, 1, c->stream);
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  (void)hipStreamSynchronize(ps);
+  hipStreamDestroy(ps);
+  float t = 0;
+  HIP_TRY(c, hipEventElapsedTime(&t, e0, e1));
+  hipEventDestroy(e0);
+  hipEventDestroy(e1);
+  *ns_per_issue = (float)((double)t * 1e6 / reps / (2048.0 * 32 * 8));
+  std::vector<unsigned long long> h(2 * (size_t)MAXS + 2);
+  HIP_TRY(c, hipMemcpy(h.data(), d_s, h.size() * 8, hipMemcpyDeviceToHost));
+  const int n = ((const int*)&h[2 * (size_t)MAXS])[1];
+  *mhz = 0;
+  if (n >= 8) {
+    const int lo = n / 4;
+    const double dt = (double)(h[2 * (size_t)(n - 1) + 1] - h[2 * (size_t)lo + 1]), dc = (double)(h[2 * (size_t)(n - 1)] - h[2 * (size_t)lo]);
+    if (dt > 0) *mhz = (float)(dc / dt * 100.0);
+  }
+  return BN254S_OK;
+}
+
+// bn254s_bench_ntt with the shader clock of the GPU measured while the stage runs (mhz: mean over the timed iterations,
+// mhz_min: the slowest ~10 us interval).  The probe is one wave on a second stream.
+int bn254s_bench_ntt_clock(bn254s_ctx* c, size_t ncols, int iters, float* ms, float* mhz, float* mhz_min) {
+  if (!c || !ms || !mhz || ncols == 0 || iters <= 0) return BN254S_E_INVALID_ARG;
+  HIP_TRY(c, hipSetDevice(c->device));
+  const int MAXS = 20000;
+  unsigned long long* d_s = (unsigned long long*)c->words("clk.samples", 2 * (size_t)MAXS + 2);
+  if (!d_s) return BN254S_E_OOM;
+  int* d_flags = (int*)(d_s + 2 * (size_t)MAXS);  // [0] stop, [1] samples taken
+  hipStream_t ps = nullptr;
+  HIP_TRY(c, hipStreamCreateWithFlags(&ps, hipStreamNonBlocking));
+  HIP_TRY(c, hipMemsetAsync(d_flags, 0, 8, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  k_clock_probe<<<1, 64, 0, ps>>>(d_s, d_flags, MAXS, d_flags + 1);
+  int rc = bn254s_bench_ntt(c, ncols, iters, ms);
+  (void)hipMemsetAsync(d_flags, 1, 1, c->stream);  // stop (stream-ordered after the timed launches)
+  (void)hipStreamSynchronize(c->stream);
+  (void)hipStreamSynchronize(ps);
+  hipStreamDestroy(ps);
+  if (rc != BN254S_OK) return rc;
+  std::vector<unsigned long long> h(2 * (size_t)MAXS + 2);
+  HIP_TRY(c, hipMemcpy(h.data(), d_s, h.size() * 8, hipMemcpyDeviceToHost));
+  const int n = ((const int*)&h[2 * (size_t)MAXS])[1];
+  if (n < 8) {
+    *mhz = 0;
+    if (mhz_min) *mhz_min = 0;
+    return BN254S_OK;
+  }
+  const int lo = n / 8;  // the first samples precede the first launch (and the warm-up iteration's clock ramp)
+  const double dt = (double)(h[2 * (size_t)(n - 1) + 1] - h[2 * (size_t)lo + 1]), dc = (double)(h[2 * (size_t)(n - 1)] - h[2 * (size_t)lo]);
+  *mhz = dt > 0 ? (float)(dc / dt * 100.0) : 0.f;
+  float mn = 1e9f;
+  for (int i = lo + 1; i < n; i++) {
+    const double t = (double)(h[2 * (size_t)i + 1] - h[2 * (size_t)i - 1]), cy = (double)(h[2 * (size_t)i] - h[2 * (size_t)i - 2]);
+    if (t > 0) mn = std::min(mn, (float)(cy / t * 100.0));
+  }
+  if (mhz_min) *mhz_min = mn;
   return BN254S_OK;
 }
 

@@ -165,6 +165,57 @@ __global__ __launch_bounds__(64) void k_m2g_finish(const u64* __restrict__ o, co
   f2_store_canonical(out + 16 * k + 8, y3);
 }
 
+// hash_to_fq2 for n inputs of `len` Goldilocks elements each, one lane per input (hash_to_g2.rs:76-87): the challenger absorbs the
+// input in chunks of eight (overwrite mode; a last partial chunk, or an empty input, is permuted when the first challenge is
+// asked for), then 2 x 16 challenges are popped - eight per permutation, lane 7 first - and their low 32 bits are the
+// little-endian limbs of two 512-bit integers, each reduced modulo p: lo + hi 2^256 with both halves taken into Montgomery form.
+__device__ static constexpr u32 M2G_TWO256_MONT[FQ_NL] = {0x3b5ae02, 0x3ab61e1, 0xaa4ba8, 0x3e9cdb2, 0x2f6ebb, 0x4553ac, 0x116483a, 0x468428, 0x236e920, 0x33056};  // 2^256 R mod p
+__global__ __launch_bounds__(64) void k_hash_to_fq2(const u64* __restrict__ in, size_t n, size_t len, u64* __restrict__ out) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const u64* x = in + k * len;
+  u64 st[12];
+#pragma unroll
+  for (int i = 0; i < 12; i++) st[i] = 0;
+  size_t pos = 0;
+  bool have_out = false;
+  for (; len - pos >= 8; pos += 8) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) st[i] = x[pos + i];
+    poseidon_permute(st);
+    have_out = true;
+  }
+  const int rem = (int)(len - pos);
+  if (rem > 0 || !have_out) {
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+      if (i < rem) st[i] = x[pos + i];
+    poseidon_permute(st);
+  }
+  fq r2, c256;
+#pragma unroll
+  for (int i = 0; i < FQ_NL; i++) {
+    r2.l[i] = FQ_R2[i];
+    c256.l[i] = M2G_TWO256_MONT[i];
+  }
+#pragma unroll 1
+  for (int coord = 0; coord < 2; coord++) {
+    u64 w[8];  // the 512-bit integer as eight 64-bit words: limb 2j | limb 2j+1 << 32
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+      if (coord + half > 0) poseidon_permute(st);  // output buffer used up (8 challenges per permutation)
+#pragma unroll
+      for (int j = 0; j < 4; j++) w[4 * half + j] = (u64)(u32)st[7 - 2 * j] | ((u64)(u32)st[6 - 2 * j] << 32);
+    }
+    const fq lo = fq_mul(fq_unpack(w), r2), hi = fq_mul(fq_unpack(w + 4), r2);  // (values below 2^256 < 6 p: loose operands)
+    const fqw c = fq_to_canonical(fq_add(lo, fq_mul(hi, c256)));
+#pragma unroll
+    for (int i = 0; i < 4; i++) out[8 * k + 4 * coord + i] = c.l[i];
+  }
+#endif
+}
+
 #define MCHK(call)                                                \
   do {                                                            \
     hipError_t e_ = (call);                                       \
@@ -212,6 +263,22 @@ extern "C" int bn254s_hash_to_fq2(const uint64_t* input, size_t len, uint64_t* o
     }
     memcpy(out + 4 * coord, r, 32);
   }
+  return BN254S_OK;
+}
+
+// The same for n inputs at once on the device (inputs[n][len] -> out[n][8]): the step before bn254s_map_to_g2 when a circuit hashes
+// many messages to G2.
+extern "C" int bn254s_hash_to_fq2_batch(bn254s_ctx* c, const uint64_t* inputs, size_t n, size_t len, uint64_t* out) {
+  if (!c || !out || (!inputs && len) || n == 0) return BN254S_E_INVALID_ARG;
+  HIP_TRY(c, hipSetDevice(c->device));
+  u64* d_in = c->words("h2f.in", n * len + 1);
+  u64* d_out = c->words("h2f.out", n * 8);
+  if (!d_in || !d_out) return BN254S_E_OOM;
+  if (len) HIP_TRY(c, hipMemcpyAsync(d_in, inputs, n * len * 8, hipMemcpyHostToDevice, c->stream));
+  k_hash_to_fq2<<<(unsigned)((n + 63) / 64), 64, 0, c->stream>>>(d_in, n, len, d_out);
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipMemcpyAsync(out, d_out, n * 64, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
   return BN254S_OK;
 }
 

@@ -771,10 +771,13 @@ int bn254s_prove_batch_begin(bn254s_ctx* c, int kind, const bn254s_params* param
   const size_t PW = point_words(kind);
   for (size_t i = 0; i < n_proofs; i++) proofs_out[i] = nullptr;
   HIP_TRY(c, hipSetDevice(c->device));
-  // proofs in flight (one stream, host thread and workspace each; GPU_MAX_HW_QUEUES = 16 gives every stream its own hardware
-  // queue).  With batches queued back to back (bench.py: two steps open) 8 / 10 / 12 / 14 / 16 slots give 81.0 / 83.0 / 84.0-84.7 /
-  // 85.0 / 84.3 proofs/s; one batch of eight proofs alone uses eight of them.
-  size_t n_slots = 12;
+  // proofs in flight (one stream, host thread and workspace each; the streams share GPU_MAX_HW_QUEUES = 16 hardware queues - more
+  // queues than that collapse the throughput: 24 / 32 queues gave 62 / 51 proofs/s).  Round 3, with arrival-order admission of the
+  // wide sections: every queued proof should find a slot at once (32 proofs queued on 24 slots: 77.8 proofs/s; on 32 slots: 87.9),
+  // and more proofs in flight keep a wide section ready at all times - bench.py with 8 / 16 / 24 / 32 proofs queued and as many
+  // slots: 83.9 / 84.8 / 87.3 / 87.9 proofs/s (tools/gpu_depth_sweep.sh, gpu_depth_sweep2.sh); 48: 67.  A slot that is never used
+  // costs a stream; its workspace (~4 GB for a 2^16-row proof) is allocated on first use.
+  size_t n_slots = 32;
   if (const char* e = getenv("BN254S_SLOTS")) n_slots = std::min((size_t)bn254s_ctx::MAX_SLOTS, (size_t)std::max(1, atoi(e)));
   for (size_t s = 0; s < n_slots; s++)
     if (!c->slot(s)) return BN254S_E_HIP;

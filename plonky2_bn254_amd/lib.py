@@ -74,9 +74,12 @@ def load_library():
                                        C.c_size_t]
     lib.bn254s_map_to_g2.argtypes = [vp, C.POINTER(Params), vp, vp, C.c_size_t, vp, vp, vp, C.POINTER(vp), C.POINTER(vp)]
     lib.bn254s_hash_to_fq2.argtypes = [vp, C.c_size_t, vp]
+    lib.bn254s_hash_to_fq2_batch.argtypes = [vp, vp, C.c_size_t, C.c_size_t, vp]
     lib.bn254s_ctl_values.argtypes = [C.c_int, vp, vp, vp, vp, C.c_size_t, vp, vp]
     lib.bn254s_commit_values.argtypes = [vp, vp, C.c_size_t, vp, vp, vp]
     lib.bn254s_bench_ntt.argtypes = [vp, C.c_size_t, C.c_int, C.POINTER(C.c_float)]
+    lib.bn254s_bench_ntt_clock.argtypes = [vp, C.c_size_t, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    lib.bn254s_bench_issue.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     lib.bn254s_poseidon_permute.argtypes = [vp, vp, C.c_size_t]
     lib.bn254s_selftest_field.argtypes = [vp, vp, vp, C.c_size_t, vp]
     lib.bn254s_selftest_fq_inv.argtypes = [vp, vp, C.c_size_t, vp]
@@ -287,6 +290,14 @@ class Context:
         return (pts, fq_jobs, g2_jobs, [Proof(self._lib, C.c_void_p(pf[i])) for i in range(n_fq)],
                 [Proof(self._lib, C.c_void_p(pg[i])) for i in range(n_g2)])
 
+    def hash_to_fq2_batch(self, inputs: np.ndarray) -> np.ndarray:
+        """inputs [n, len] Goldilocks elements -> u [n, 8]: hash_to_fq2 (hash_to_g2.rs:76-87) of every row, on the device."""
+        inputs = np.ascontiguousarray(inputs, dtype=np.uint64)
+        n, ln = inputs.shape
+        out = np.zeros((n, 8), np.uint64)
+        self._check(self._lib.bn254s_hash_to_fq2_batch(self._h, _ptr(inputs) if ln else None, n, ln, _ptr(out)), "bn254s_hash_to_fq2_batch")
+        return out
+
     def ctl_values(self, kind, scalars, x, offset, outputs):
         """(input rows [n, 81|145|33], output rows [n, 33|65|17]): the extra looking values of the two CTLs."""
         n = scalars.shape[0]
@@ -313,6 +324,18 @@ class Context:
         ms = C.c_float()
         self._check(self._lib.bn254s_bench_ntt(self._h, ncols, iters, C.byref(ms)), "bn254s_bench_ntt")
         return ms.value
+
+    def bench_ntt_clock(self, ncols: int, iters: int = 10):
+        """(ms per stage, mean shader MHz, slowest-interval MHz) of the NTT/LDE stage alone on the GPU."""
+        ms, mhz, mn = C.c_float(), C.c_float(), C.c_float()
+        self._check(self._lib.bn254s_bench_ntt_clock(self._h, ncols, iters, C.byref(ms), C.byref(mhz), C.byref(mn)), "bn254s_bench_ntt_clock")
+        return ms.value, mhz.value, mn.value
+
+    def bench_issue(self):
+        """(ns per wave-instruction and SIMD of the half-rate vector class at 8 waves per SIMD, shader MHz meanwhile)."""
+        ns, mhz = C.c_float(), C.c_float()
+        self._check(self._lib.bn254s_bench_issue(self._h, C.byref(ns), C.byref(mhz)), "bn254s_bench_issue")
+        return ns.value, mhz.value
 
     def bench_copy(self, words: int, iters: int = 3):
         self._check(self._lib.bn254s_bench_copy(self._h, words, iters), "bn254s_bench_copy")

@@ -128,7 +128,10 @@ def _run_bench_2_ranks(extra, port, timeout):
     """`python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2 ...` as a fresh child process: two gloo ranks on
     the one GPU of this box (BENCH_BACKEND=gloo BENCH_DEVICE=0; the driver's 8-GPU run uses nccl and one GPU per rank - the rest of
     the code path is the same)."""
-    env = dict(os.environ, BENCH_BACKEND="gloo", BENCH_DEVICE="0", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    # (two ranks share this box's one GPU and its memory: 16 slots and one step in flight per rank instead of the 32 / 2 a rank
+    # has to itself on its own GPU)
+    env = dict(os.environ, BENCH_BACKEND="gloo", BENCH_DEVICE="0", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0",
+               BN254S_SLOTS="16")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2"] + extra
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
@@ -140,7 +143,7 @@ def _run_bench_2_ranks(extra, port, timeout):
 
 def test_bench_two_ranks_g1_child_process(gpu_ctx):
     gpu_ctx.trim()        # the two child processes need the device memory this process's idle workspaces hold
-    out = _run_bench_2_ranks(["--steps", "2", "--warmup", "1", "--no-extras", "--no-cpu-baseline"], 29711, 900)
+    out = _run_bench_2_ranks(["--steps", "2", "--warmup", "1", "--steps-in-flight", "1", "--no-extras", "--no-cpu-baseline"], 29711, 900)
     assert out["n_gpus"] == 2 and out["steps"] == 2 and out["warmup"] == 1 and out["scaling"] == "weak"
     assert out["unit"] == "proofs/s" and out["value"] > 0 and out["higher_is_better"] is True
     assert out["config"]["proofs_per_step_per_gpu"] == 16 and "configs[3] shard: 2048 G1 scalar-muls" in out["config"]["workload"]

@@ -118,3 +118,36 @@ def test_hash_to_fq2_host_function_matches_python():
         out = np.zeros(8, np.uint64)
         assert lib.bn254s_hash_to_fq2(L._ptr(inp), inp.size, L._ptr(out)) == 0
         assert (synth.words_to_int(out[:4]), synth.words_to_int(out[4:])) == m2g.hash_to_fq2(inp.tolist()), k
+
+
+@pytest.mark.gpu
+def test_hash_to_fq2_batch_on_device_equals_host_and_python(gpu_ctx):
+    """bn254s_hash_to_fq2_batch (one lane per message: device challenger + 512-bit reduction in the 26-bit-limb field) against the
+    host function and the pure-Python mirror, for every input length class (empty, partial chunk, exactly one / two chunks,
+    ragged), edge elements, and a batch of 4096 messages (the input count of configs[4])."""
+    import plonky2_bn254_amd.lib as L
+    lib = L.load_library()
+    rng = np.random.default_rng(77)
+    for ln in (0, 1, 7, 8, 9, 16, 21):
+        inp = rng.integers(0, m2g.GL_P, size=(5, ln), dtype=np.uint64)
+        if ln:
+            inp[0, :] = m2g.GL_P - 1
+            inp[1, :] = 0
+        got = gpu_ctx.hash_to_fq2_batch(inp)
+        for k in range(5):
+            want = m2g.hash_to_fq2(inp[k].tolist())
+            assert (synth.words_to_int(got[k, :4]), synth.words_to_int(got[k, 4:])) == want, (ln, k)
+            host = np.zeros(8, np.uint64)
+            row = np.ascontiguousarray(inp[k])
+            assert lib.bn254s_hash_to_fq2(L._ptr(row) if ln else None, ln, L._ptr(host)) == 0
+            assert np.array_equal(host, got[k])
+    big = rng.integers(0, m2g.GL_P, size=(4096, 12), dtype=np.uint64)
+    got = gpu_ctx.hash_to_fq2_batch(big)
+    for k in (0, 1, 2047, 4095):
+        assert (synth.words_to_int(got[k, :4]), synth.words_to_int(got[k, 4:])) == m2g.hash_to_fq2(big[k].tolist())
+    assert len({r.tobytes() for r in got}) == 4096
+    # and onward: the hashed values are valid inputs of bn254s_map_to_g2 (the reference's hash_to_g2 = the two together)
+    _, _, off = synth.g2_inputs(4, seed=5)
+    pts, fq_jobs, g2_jobs, pf, pg = gpu_ctx.map_to_g2(np.ascontiguousarray(got[:4]), off)
+    gpu_ctx.verify(1, pg[0].words, pg[0].degree_bits, np.ascontiguousarray(g2_jobs[:, :4]), np.ascontiguousarray(g2_jobs[:, 4:]), off,
+                   pg[0].outputs)
