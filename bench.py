@@ -90,20 +90,46 @@ def gather_caps(local_caps: np.ndarray, dist, device):
     return torch.stack(out).cpu().numpy().view(np.uint64)
 
 
+def host_cpu_share() -> int:
+    """Cores this process may actually use: the cgroup CPU quota when there is one (a GPU box of the pool gives a one-GPU job 16 of
+    its 256 hardware threads: more OpenMP threads than that only contend - 4.2 / 5.2 / 6.5 / 7.7 s per proof with 16 / 32 / 64 /
+    128 threads, tools/oracle_threads.py), else the visible CPUs; at most 32."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(txt[0]) // int(txt[1])))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    n = min(n, max(1, q // int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, min(n, 32))
+
+
 def cpu_baseline():
     """Times ONE 128-instance proof with the CPU oracle (same algorithm, OpenMP) on the host cores."""
     from tests import oracle_lib
     from tools import synth
     lib = oracle_lib.load()
-    # the restatement is fastest at 24-48 threads on the 256-thread hosts of the pool (10.3 s against 20 s with all of them)
+    threads = int(os.environ.get("BENCH_CPU_THREADS", "0")) or min(16, host_cpu_share())
     if hasattr(lib, "orc_set_num_threads"):
-        lib.orc_set_num_threads(min(32, os.cpu_count() or 1))
+        lib.orc_set_num_threads(threads)
     s, x, o = synth.g1_inputs(INSTANCES_PER_PROOF)
     t0 = time.time()
     oracle_lib.g1_prove(lib, s, x, o)
     dt = time.time() - t0
     return {"value": round(1.0 / dt, 5), "unit": "proofs/s", "cores": int(lib.orc_num_threads()), "kind": "port",
-            "sample": "1 proof of 128 G1 scalar-muls (2^16 rows), CPU restatement (oracle/), %.1f s" % dt}
+            "sample": "1 proof of 128 G1 scalar-muls (2^16 rows), CPU restatement (oracle/: sparse-partial-round Poseidon, radix-2 "
+                      "NTT, OpenMP), %.1f s" % dt}
 
 
 def other_kinds(ctx, synth):

@@ -180,18 +180,18 @@ struct bn254s_ctx : BufPool {
   std::mutex big_mu;
   std::condition_variable big_cv;
   // Weighted semaphore over the GPU-filling sections of all proofs in flight, admission in arrival order.  Classes (cost out
-  // of big_cap = 9):
-  //   BIG_NTT  (9): the NTT/LDE stage runs alone - it is the stage the roofline figure is quoted on;
-  //   BIG_EXCL (3): quotient, auxiliary columns, range-check histogram, openings, FRI combine;
-  //   BIG_HASH (3): Poseidon leaf hashing (one 2^17-leaf launch puts two waves on a SIMD);
-  // so three of the cost-3 sections share the GPU.  Arrival order matters: without it a waiting NTT stage (which needs the whole
-  // capacity) was overtaken by later cost-3 sections - at the start of a call by the range-check histograms of all the other
-  // proofs - and the first wide arithmetic of a step started milliseconds late.  Repeating one batch (tools/step_overheads.py):
-  // 74.4-75.1 -> 77.4-77.9 proofs/s for the order alone, 78.9-79.6 with three concurrent sections; bench.py, whose steps prove
-  // fresh inputs and end on the slowest proof-of-work search of eight, measures no difference (76 either way).
-  // BN254S_BIG_CAP / BN254S_BIG_COST_NTT / BN254S_BIG_COST_EXCL / BN254S_BIG_COST_HASH / BN254S_SCHED_FIFO override (tuning only; FIFO admission
-  // is the default, BN254S_SCHED_FIFO=0 switches it off).
-  int big_cap = 9, big_cost[3] = {9, 3, 3}, big_used = 0;
+  // of big_cap = 12):
+  //   BIG_NTT  (12): the NTT/LDE stage runs alone - it is the stage the roofline figure is quoted on, and it fills the machine;
+  //   BIG_HASH  (4): Poseidon leaf hashing (a 2^17-leaf launch puts two 127-register waves on every SIMD: three at a time);
+  //   BIG_EXCL  (2): quotient, auxiliary columns, range-check histogram, openings, FRI combine;
+  // Arrival order matters: without it a waiting NTT stage (which needs the whole capacity) is overtaken by later, cheaper
+  // sections - at the start of a call by the range-check histograms of all the other proofs - and the first wide arithmetic
+  // of a step starts milliseconds late.  Round 3 (bench.py, 32 proofs queued on 32 slots, tools/gpu_cost_sweep.sh): capacity 9
+  // with costs 9 / 3 / 3 (round 2) 86.0-86.5 proofs/s; 12 with 12 / 3 / 3: 87.4-88.5; 12 with 12 / 4 / 2: 88.5-88.9; 15 with
+  // 15 / 3 / 3: 88.2; 18: 85.6; an NTT stage that shares the GPU (cost 6 of 9) gains 3 % and doubles its own time.
+  // BN254S_BIG_CAP / BN254S_BIG_COST_NTT / BN254S_BIG_COST_EXCL / BN254S_BIG_COST_HASH / BN254S_SCHED_FIFO override (tuning only; FIFO
+  // admission is the default, BN254S_SCHED_FIFO=0 switches it off).
+  int big_cap = 12, big_cost[3] = {12, 2, 4}, big_used = 0;  // indexed by BIG_NTT, BIG_EXCL, BIG_HASH
   bool big_fifo = true;  // BN254S_SCHED_FIFO=0: the unordered semaphore (A/B runs)
   unsigned long big_ticket = 0, big_serving = 0;
   void big_lock(int cls) {

@@ -70,6 +70,18 @@ template <bool INV, int MODE>
 __device__ __forceinline__ void dft256_tile(u64* x, u32* lds, const u64* __restrict__ tw256, int& d, int& g) {
   dft16<INV>(x);
   // inner twiddle w_256^(g*ka), then transpose (g <-> ka) through LDS
+#if defined(BN254S_NTT_AB) && BN254S_NTT_AB == 1
+  // TIMING-ONLY build (tools/gpu_ntt_ab.sh, wrong results): the inner twiddles of the pass-1 tiles dropped = the upper bound of
+  // what a 64 x 64 x 16 decomposition (one general twiddle layer fewer per transform) could save
+  if (MODE != 0)
+#endif
+#if defined(BN254S_NTT_AB) && BN254S_NTT_AB == 2
+  // TIMING-ONLY build: ... replaced by power-of-two twiddles (what a radix-64 stage would put there instead)
+  if (MODE == 0) {
+#pragma unroll
+    for (int ka = 1; ka < 16; ka++) x[br4(ka)] = (ka & 1) ? gl_shl_asm<36>(x[br4(ka)]) : gl_shl_asm<12>(x[br4(ka)]);
+  } else
+#endif
 #pragma unroll
   for (int ka = 1; ka < 16; ka++) x[br4(ka)] = gl_mul_asm(x[br4(ka)], tw256[g * ka]);
   int d2 = d, g2 = g;

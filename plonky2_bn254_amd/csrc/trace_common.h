@@ -52,8 +52,16 @@ __device__ static constexpr u32 PINV288[9] = {0x1b799c77u, 0x782df87du, 0xe13595
 
 // generate_modulus_zero (modulus_zero.rs:77-123): in = 31 signed limb coefficients of a multiple of p.
 // Writes the 80 witness values to columns col0.. of `row` (trace column-major, N rows).
-static __device__ __noinline__ void gen_modulus_zero(const long long* in, u64* __restrict__ trace, size_t N, size_t row, int col0,
-                                              int* err) {
+// The function is called four to ten times per row and is not inlined; its 31 inputs travel through LDS (coefficient i of the
+// calling lane at in[i * MZ_LANES]: one wave per workgroup, a lane reads only what it wrote) - as a by-pointer argument they
+// sat in scratch memory (256 B per lane in round 2).
+static constexpr int MZ_LANES = 64;
+typedef __attribute__((address_space(3))) long long mz_lds_t;
+static __device__ __noinline__ void gen_modulus_zero_lds(const mz_lds_t* in_lds, u64* __restrict__ trace, size_t N, size_t row, int col0,
+                                                         int* err) {
+  long long in[31];
+#pragma unroll
+  for (int i = 0; i < 31; i++) in[i] = in_lds[i * MZ_LANES];
   // low 288 bits of V = sum in[i] 2^(16 i), two's complement
   u32 v[9];
   long long carry = 0;
@@ -119,6 +127,16 @@ static __device__ __noinline__ void gen_modulus_zero(const long long* in, u64* _
   }
   // exactness: the last carry must vanish, otherwise `in` was not a multiple of p
   if (bad || a != constr[31]) atomicCAS(err, 0, BN254S_E_INTERNAL);
+}
+
+// stores the coefficients to the calling lane's LDS slots and calls the function above; `slots` = &buffer[0][lane] of a
+// __shared__ long long buffer[31][MZ_LANES]
+__device__ __forceinline__ void gen_modulus_zero(const long long* in, long long* slots, u64* __restrict__ trace, size_t N, size_t row,
+                                                 int col0, int* err) {
+  mz_lds_t* l = (mz_lds_t*)slots;
+#pragma unroll
+  for (int i = 0; i < 31; i++) l[i * MZ_LANES] = in[i];
+  gen_modulus_zero_lds(l, trace, N, row, col0, err);
 }
 
 __device__ __forceinline__ void pol_mul16(const int* a, const int* b, long long* out /*31*/) {

@@ -419,11 +419,13 @@ __global__ __launch_bounds__(64) void k_g1_rows(const u64* __restrict__ scalars,
   int dx[16];
 #pragma unroll
   for (int i = 0; i < 16; i++) dx[i] = bx[i] - ax[i];
+  __shared__ long long mz_buf[31][MZ_LANES];  // the arguments of gen_modulus_zero (trace_common.h)
+  long long* const mz_slots = &mz_buf[0][threadIdx.x];
   long long diff[31], tmp[31];
   // is_modulus_zero witness: delta_x * inv - 1 + is_zero   (is_modulus_zero.rs:57-59)
   pol_mul16(dx, invl, diff);
   diff[0] += (long long)is_x_eq - 1;
-  gen_modulus_zero(diff, trace, N, r, G1_COL_AUX + G1_AUX_IS_X_EQ_AUX + 16, err);
+  gen_modulus_zero(diff, mz_slots, trace, N, r, G1_COL_AUX + G1_AUX_IS_X_EQ_AUX + 16, err);
   // lambda witness
   if (!x_eq) {
     pol_mul16(lam, dx, diff);  // lambda*(b.x-a.x) - (b.y-a.y)
@@ -435,19 +437,19 @@ __global__ __launch_bounds__(64) void k_g1_rows(const u64* __restrict__ scalars,
 #pragma unroll
     for (int i = 0; i < 31; i++) diff[i] = 2 * diff[i] - 3 * tmp[i];
   }
-  gen_modulus_zero(diff, trace, N, r, G1_COL_AUX + G1_AUX_LAMBDA_AUX, err);
+  gen_modulus_zero(diff, mz_slots, trace, N, r, G1_COL_AUX + G1_AUX_LAMBDA_AUX, err);
   // x witness: lambda^2 - (a.x + b.x + c.x)
   pol_mul16(lam, lam, diff);
 #pragma unroll
   for (int i = 0; i < 16; i++) diff[i] -= (long long)(ax[i] + bx[i] + cx[i]);
-  gen_modulus_zero(diff, trace, N, r, G1_COL_AUX + G1_AUX_X_AUX, err);
+  gen_modulus_zero(diff, mz_slots, trace, N, r, G1_COL_AUX + G1_AUX_X_AUX, err);
   // y witness: lambda*(c.x - a.x) + c.y + a.y
 #pragma unroll
   for (int i = 0; i < 16; i++) t16[i] = cx[i] - ax[i];
   pol_mul16(lam, t16, diff);
 #pragma unroll
   for (int i = 0; i < 16; i++) diff[i] += (long long)(cy[i] + ay[i]);
-  gen_modulus_zero(diff, trace, N, r, G1_COL_AUX + G1_AUX_Y_AUX, err);
+  gen_modulus_zero(diff, mz_slots, trace, N, r, G1_COL_AUX + G1_AUX_Y_AUX, err);
 
   // bits rotated left by k (scalar_mul_stark.rs:163-167), flags and bookkeeping columns
   for (int i = 0; i < 256; i++) {

@@ -328,6 +328,8 @@ __global__ __launch_bounds__(64) void k_g2_rows(const u64* __restrict__ scalars,
   put(L::AUX + G2_AUX_IS_C1_ZERO, z1);
   put(L::AUX + G2_AUX_IS_X_EQ_FILTER, x_eq);
 
+  __shared__ long long mz_buf[31][MZ_LANES];  // the arguments of gen_modulus_zero (trace_common.h)
+  long long* const mz_slots = &mz_buf[0][threadIdx.x];
   long long diff[31];
   int dx0[16], dx1[16];
 #pragma unroll
@@ -340,12 +342,12 @@ __global__ __launch_bounds__(64) void k_g2_rows(const u64* __restrict__ scalars,
   put16(L::AUX + G2_AUX_C0_AUX, t0);
   pol_mul16(dx0, t0, diff);
   diff[0] += (long long)z0 - 1;
-  gen_modulus_zero(diff, trace, N, r, L::AUX + G2_AUX_C0_AUX + 16, err);
+  gen_modulus_zero(diff, mz_slots, trace, N, r, L::AUX + G2_AUX_C0_AUX + 16, err);
   fq_to_limbs(inv1, t0);
   put16(L::AUX + G2_AUX_C1_AUX, t0);
   pol_mul16(dx1, t0, diff);
   diff[0] += (long long)z1 - 1;
-  gen_modulus_zero(diff, trace, N, r, L::AUX + G2_AUX_C1_AUX + 16, err);
+  gen_modulus_zero(diff, mz_slots, trace, N, r, L::AUX + G2_AUX_C1_AUX + 16, err);
   // lambda witness
   fq_to_limbs(b.y.c0, t0);  // b.y
   fq_to_limbs(b.y.c1, t1);
@@ -355,33 +357,33 @@ __global__ __launch_bounds__(64) void k_g2_rows(const u64* __restrict__ scalars,
     ext_mul_c0(l0, l1, dx0, dx1, diff);
 #pragma unroll
     for (int i = 0; i < 16; i++) diff[i] -= (long long)(t0[i] - ay0[i]);
-    gen_modulus_zero(diff, trace, N, r, L::AUX + G2_AUX_LAMBDA_AUX, err);
+    gen_modulus_zero(diff, mz_slots, trace, N, r, L::AUX + G2_AUX_LAMBDA_AUX, err);
     ext_mul_c1(l0, l1, dx0, dx1, diff);
 #pragma unroll
     for (int i = 0; i < 16; i++) diff[i] -= (long long)(t1[i] - ay1[i]);
-    gen_modulus_zero(diff, trace, N, r, L::AUX + G2_AUX_LAMBDA_AUX + 80, err);
+    gen_modulus_zero(diff, mz_slots, trace, N, r, L::AUX + G2_AUX_LAMBDA_AUX + 80, err);
   } else {
     long long xx[31];
     ext_mul_c0(l0, l1, ay0, ay1, diff);
     ext_mul_c0(ax0, ax1, ax0, ax1, xx);
 #pragma unroll
     for (int i = 0; i < 31; i++) diff[i] = 2 * diff[i] - 3 * xx[i];
-    gen_modulus_zero(diff, trace, N, r, L::AUX + G2_AUX_LAMBDA_AUX, err);
+    gen_modulus_zero(diff, mz_slots, trace, N, r, L::AUX + G2_AUX_LAMBDA_AUX, err);
     ext_mul_c1(l0, l1, ay0, ay1, diff);
     ext_mul_c1(ax0, ax1, ax0, ax1, xx);
 #pragma unroll
     for (int i = 0; i < 31; i++) diff[i] = 2 * diff[i] - 3 * xx[i];
-    gen_modulus_zero(diff, trace, N, r, L::AUX + G2_AUX_LAMBDA_AUX + 80, err);
+    gen_modulus_zero(diff, mz_slots, trace, N, r, L::AUX + G2_AUX_LAMBDA_AUX + 80, err);
   }
   // x witness: lambda^2 - (a.x + b.x + c.x)
   ext_mul_c0(l0, l1, l0, l1, diff);
 #pragma unroll
   for (int i = 0; i < 16; i++) diff[i] -= (long long)(ax0[i] + bx0[i] + cx0[i]);
-  gen_modulus_zero(diff, trace, N, r, L::AUX + G2_AUX_X_AUX, err);
+  gen_modulus_zero(diff, mz_slots, trace, N, r, L::AUX + G2_AUX_X_AUX, err);
   ext_mul_c1(l0, l1, l0, l1, diff);
 #pragma unroll
   for (int i = 0; i < 16; i++) diff[i] -= (long long)(ax1[i] + bx1[i] + cx1[i]);
-  gen_modulus_zero(diff, trace, N, r, L::AUX + G2_AUX_X_AUX + 80, err);
+  gen_modulus_zero(diff, mz_slots, trace, N, r, L::AUX + G2_AUX_X_AUX + 80, err);
   // y witness: lambda*(c.x - a.x) + c.y + a.y
   fq_to_limbs(c.y.c0, t0);
   fq_to_limbs(c.y.c1, t1);
@@ -395,11 +397,11 @@ __global__ __launch_bounds__(64) void k_g2_rows(const u64* __restrict__ scalars,
   ext_mul_c0(l0, l1, u0, u1, diff);
 #pragma unroll
   for (int i = 0; i < 16; i++) diff[i] += (long long)(t0[i] + ay0[i]);
-  gen_modulus_zero(diff, trace, N, r, L::AUX + G2_AUX_Y_AUX, err);
+  gen_modulus_zero(diff, mz_slots, trace, N, r, L::AUX + G2_AUX_Y_AUX, err);
   ext_mul_c1(l0, l1, u0, u1, diff);
 #pragma unroll
   for (int i = 0; i < 16; i++) diff[i] += (long long)(t1[i] + ay1[i]);
-  gen_modulus_zero(diff, trace, N, r, L::AUX + G2_AUX_Y_AUX + 80, err);
+  gen_modulus_zero(diff, mz_slots, trace, N, r, L::AUX + G2_AUX_Y_AUX + 80, err);
 
   for (int i = 0; i < 256; i++) {
     int src = (i + k) & 255;
@@ -535,11 +537,13 @@ __global__ __launch_bounds__(64) void k_fq_rows(const u64* __restrict__ scalars,
   fq_to_limbs(product, t);
 #pragma unroll
   for (int i = 0; i < 16; i++) put(L::SUM + i, t[i]);
+  __shared__ long long mz_buf[31][MZ_LANES];  // the arguments of gen_modulus_zero (trace_common.h)
+  long long* const mz_slots = &mz_buf[0][threadIdx.x];
   long long diff[31];
   pol_mul16(al, bl, diff);  // a*b - c  (fields/mul.rs:34-38)
 #pragma unroll
   for (int i = 0; i < 16; i++) diff[i] -= (long long)cl[i];
-  gen_modulus_zero(diff, trace, N, r, L::AUX, err);
+  gen_modulus_zero(diff, mz_slots, trace, N, r, L::AUX, err);
   for (int i = 0; i < 256; i++) {
     int src = (i + k) & 255;
     put(L::BITS + i, (s[src >> 6] >> (src & 63)) & 1);

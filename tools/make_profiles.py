@@ -50,6 +50,7 @@ def main():
     per_perm = valu_per_wave / 98
     alu = {"leaf_hash_valu_wave_insts_per_launch_781x2e17": 2048 * valu_per_wave, "valu_insts_per_permutation": round(per_perm, 1),
            "salu_insts_per_permutation": round(salu_per_wave / 98, 1),
+           "full_rate_share": 0.1576,   # tools/gen_poseidon_asm.py: 2024 of the 12846 instructions are v_mov_b32 / v_sub_u32 / v_min_u32
            "valu_peak_wave_insts_per_s": peak, "peak_definition": "1024 SIMDs x 2.4 GHz / %.2f cycles: issue cost of v_mad_u64_u32 (and of "
            "every other half-rate instruction) measured with 8 waves per SIMD, tools/ubench/sgpr_ops.hip" % mad8,
            "source": "profiles/%s_valu_insts.md" % R}
@@ -64,6 +65,13 @@ def main():
         if r["Counter_Name"] == "SQ_WAVES":
             calls[n] += 1
     tot = sum(v["SQ_INSTS_VALU"] for v in acc.values())
+    # executed VALU instructions per wave of the four launches of a commitment (bench.py: roofline.valu_floor)
+    pw = {n: v["SQ_INSTS_VALU"] / max(v["SQ_WAVES"], 1) for n, v in acc.items()}
+    ntt_stage = pw["k_ntt_pass1<true>"] + pw["k_ntt_intt2_lde1<8>"] + 2 * pw["k_ntt_pass2<false, true>"]
+    json.dump({"valu_insts_per_wave_stage": round(ntt_stage, 1),
+               "per_kernel": {k: round(v, 1) for k, v in pw.items() if k.startswith("k_ntt")},
+               "source": "profiles/%s_valu_insts.md (SQ_INSTS_VALU / SQ_WAVES; stage = pass1<true> + intt2_lde1<8> + 2 x pass2<false,true>)" % R},
+              open(os.path.join(DST, R + "_ntt_valu.json"), "w"), indent=1)
     with open(os.path.join(DST, R + "_valu_insts.md"), "w") as f:
         f.write("# %s - where the VALU issue slots go: `rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES -- python3 tools/run_proofs.py 2 single`\n\n" % R)
         f.write("Three single G1 proofs (128 instances, 2^16 rows; `tools/gpu_profiles.sh`).  Wave-level VALU instructions per kernel, "
@@ -73,7 +81,7 @@ def main():
                                                                v["SQ_INSTS_VALU"] / max(v["SQ_WAVES"], 1)))
         f.write("\nPoseidon leaf hashing alone (`tools/bench_hash.py` under `--pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES`, 781 columns x 2^20 "
                 "leaves): %.0f VALU + %.0f SALU instructions per wave = **%.0f VALU per permutation** (98 permutations per leaf; the "
-                "generator's count for the permutation itself is 16 412, the rest is the sponge loop: loads, round 0's constants, "
+                "generator counts 12 846 for the permutation itself, the rest is the sponge loop: loads, round 0's constants, "
                 "parking the input).  Round 1: 24.4 k (compiler output).\n" % (valu_per_wave, salu_per_wave, per_perm))
         f.write("\nIssue peak used by bench.py's `roofline_alu`: %.1f G wave-instructions/s = 1024 SIMDs x 2.4 GHz / %.2f cycles "
                 "(`%s_ubench_issue.txt`: every half-rate instruction - v_mad_u64_u32, v_lshl_add_u64, carry instructions, "
