@@ -133,25 +133,36 @@ def cpu_baseline():
 
 
 def other_kinds(ctx, synth):
-    """BASELINE.json configs[2] (1024 G2 scalar-muls) and the Fq-exp STARK of configs[4], same batch shape as the headline:
-    8 proofs x 128 instances on one GPU.  128 distinct synthetic instances are tiled 8x (python big-int G2 points are slow to
-    make); reported beside the headline, never part of `value`."""
+    """BASELINE.json configs[2] (1024 G2 scalar-muls) and the Fq-exp STARK of configs[4], same step shape as the headline: 8 proofs
+    x 128 instances per step on one GPU, four steps timed with two in flight (16 proofs queued: a G2 proof's workspace is 7 GB).
+    128 distinct synthetic instances are tiled (python big-int G2 points are slow to make), the scalars differ in every proof;
+    reported beside the headline, never part of `value`."""
     res = {}
     for name, kind, gen in (("g2_scalar_mul", 1, synth.g2_inputs), ("fq_exp", 2, synth.fq_inputs)):
         try:
-            ins = [np.tile(a, (8, 1)) for a in gen(INSTANCES_PER_PROOF)]
-            off = ins[2] if len(ins) > 2 else None
-            ctx.prove_batch(kind, ins[0], ins[1], off)
+            base = gen(INSTANCES_PER_PROOF)
+            rng = np.random.default_rng(kind)
+            steps = []
+            for _ in range(5):
+                sc = rng.integers(0, 1 << 63, size=(8 * INSTANCES_PER_PROOF, 4), dtype=np.uint64) * np.uint64(2) + \
+                    rng.integers(0, 2, size=(8 * INSTANCES_PER_PROOF, 4), dtype=np.uint64)
+                steps.append([np.ascontiguousarray(sc)] + [np.tile(a, (8, 1)) for a in base[1:]])
+
+            def begin(ins):
+                return ctx.prove_batch_begin(kind, ins[0], ins[1], ins[2] if len(ins) > 2 else None)
+            begin(steps[0]).end()          # warm-up (workspaces of this kind)
             t0 = time.perf_counter()
-            reps = 2
-            for _ in range(reps):
-                proofs = ctx.prove_batch(kind, ins[0], ins[1], off)
-            dt = (time.perf_counter() - t0) / reps
-            p = proofs[-1]
+            pending, proofs = [begin(steps[1])], None
+            for ins in steps[2:]:
+                pending.append(begin(ins))
+                proofs = pending.pop(0).end()
+            proofs = pending.pop(0).end()
+            dt = (time.perf_counter() - t0) / 4
+            ins, p = steps[4], proofs[-1]
             lo = 128 * (len(proofs) - 1)
             ctx.verify(kind, p.words, p.degree_bits, ins[0][lo:lo + 128], ins[1][lo:lo + 128],
-                       None if off is None else off[lo:lo + 128], p.outputs)
-            res[name] = {"proofs_per_s": round(8 / dt, 2), "ms_per_batch_of_8": round(dt * 1e3, 1),
+                       None if len(ins) < 3 else ins[2][lo:lo + 128], p.outputs)
+            res[name] = {"proofs_per_s": round(8 / dt, 2), "ms_per_step_of_8": round(dt * 1e3, 1), "steps_in_flight": 2,
                          "instances_per_s": round(8 * INSTANCES_PER_PROOF / dt, 1), "last_proof_verified": True}
         except Exception as e:
             res[name] = {"error": str(e)}
@@ -522,10 +533,14 @@ def main():
 
     rank, local_rank, world, dist = init_dist(args)
     dev_id = int(os.environ.get("BENCH_DEVICE", local_rank))
+    if world > 1:
+        # several ranks on one host: the 32 proof threads of a rank sleep on an interrupt while they wait for the GPU instead of
+        # spinning (one GPU: 86.1-89.5 proofs/s spinning with 33 s of CPU per run, 87.7-88.3 sleeping with 10.5 s; tools/gpu_sync_ab.sh)
+        os.environ.setdefault("BN254S_SYNC", "blocking")
+    ctx = pk.Context(dev_id)      # before torch touches the device (BN254S_SYNC is applied at the first use of a device)
     torch.cuda.set_device(dev_id)
     device = torch.device("cuda", dev_id)
     gather_device = device if os.environ.get("BENCH_BACKEND", "nccl") == "nccl" else torch.device("cpu")
-    ctx = pk.Context(dev_id)
     fn = run_g1 if args.workload == "g1" else run_map_to_g2
     out = fn(args, pk, torch, synth, ctx, rank, world, dist, device, gather_device)
     if rank == 0:

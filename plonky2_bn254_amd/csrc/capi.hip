@@ -1,6 +1,7 @@
 // C ABI of libbn254stark.so (include/bn254_stark.h): context management and kernel-level entry points.
 // The proving entry points live in prover.hip.
 #include <algorithm>
+#include <cstring>
 #include "ctx.h"
 #include "merkle.h"
 #include "trace_g1.h"
@@ -45,6 +46,11 @@ int bn254s_ctx_create(int device_id, bn254s_ctx** out) {
   *out = nullptr;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || device_id < 0 || device_id >= ndev) return BN254S_E_HIP;
+  // BN254S_SYNC=blocking: host threads waiting for the GPU sleep on an interrupt instead of spinning (takes effect only if this is
+  // the first use of the device in the process; with N ranks x 32 proof threads on one host the spinning threads outnumber the cores)
+  if (const char* e = getenv("BN254S_SYNC"))
+    if (!strcmp(e, "blocking")) (void)hipSetDeviceFlags(hipDeviceScheduleBlockingSync);
+  (void)hipGetLastError();
   if (hipSetDevice(device_id) != hipSuccess) return BN254S_E_HIP;
   bn254s_ctx* c = new bn254s_ctx();
   c->device = device_id;

@@ -21,6 +21,14 @@
 #include "gl_asm.h"
 #include "ntt.h"
 
+// Issue priority of the NTT/LDE kernels' waves (0 = default).  The stage runs alone among the wide kernels, but the latency-bound
+// kernels of the other proofs in flight (priority 3, gl_dev.h) share its SIMDs; BN254S_NTT_PRIO is a compile-time A/B knob.
+#if defined(__HIP_DEVICE_COMPILE__) && defined(BN254S_NTT_PRIO) && BN254S_NTT_PRIO > 0
+#define NTT_KERNEL_PRIO() __builtin_amdgcn_s_setprio(BN254S_NTT_PRIO)
+#else
+#define NTT_KERNEL_PRIO() ((void)0)
+#endif
+
 // ---- radix-16 DFT in registers --------------------------------------------------------------------------
 template <bool INV, int SPAN, int G, int J>
 __device__ __forceinline__ void bfly16(u64* x) {
@@ -123,6 +131,7 @@ __global__ __launch_bounds__(256) void k_ntt_pass1(const u64* __restrict__ in, s
                                                    size_t out_stride, const u64* __restrict__ pre,
                                                    const u64* __restrict__ twmat, const u64* __restrict__ tw256,
                                                    unsigned log_r) {
+  NTT_KERNEL_PRIO();
   __shared__ u32 lds[LDS_TILE_WORDS];
   const int t = threadIdx.x;
   int d = t & 15, g = t >> 4;
@@ -156,6 +165,7 @@ template <bool INV, bool OUT_BITREV>
 __global__ __launch_bounds__(256, 4) void k_ntt_pass2(const u64* __restrict__ in, size_t in_stride, u64* __restrict__ out,
                                                    size_t out_stride, const u64* __restrict__ post, u64 post_scalar,
                                                    const u64* __restrict__ tw256, unsigned log_r) {
+  NTT_KERNEL_PRIO();
   __shared__ __attribute__((aligned(16))) u32 lds[OUT_BITREV ? 16 * STAGE_ROW * 4 : LDS_TILE_WORDS];  // exchange image, then the store staging
   const int t = threadIdx.x;
   int g = t & 15, d = t >> 4;
@@ -223,6 +233,7 @@ __global__ __launch_bounds__(256, NPARK ? 4 : 3) void k_ntt_intt2_lde1(const u64
                                                         const u64* __restrict__ pre0, const u64* __restrict__ pre1,
                                                         const u64* __restrict__ twmat, const u64* __restrict__ tw256_fwd,
                                                         unsigned log_r) {
+  NTT_KERNEL_PRIO();
   __shared__ u32 lds[LDS_TILE_WORDS];
   // NPARK of the thread's sixteen coefficients wait in LDS between the two coset transforms: with 8 of them there the kernel
   // needs 122 registers and 33 KB of LDS, four workgroups per CU (1.76 ms per 1237-column stage against 1.84 ms with all

@@ -9,7 +9,8 @@ from typing import Optional
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libbn254stark.so")
+# BN254S_LIB: another build of the same library (A/B measurements of compile-time knobs, tools/ubench/ab/); never a fallback
+LIB_PATH = os.environ.get("BN254S_LIB") or os.path.join(_HERE, "libbn254stark.so")
 
 U64P = C.POINTER(C.c_uint64)
 

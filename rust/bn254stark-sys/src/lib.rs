@@ -66,6 +66,10 @@ extern "C" {
                            offset: *const u64, n: usize, out: *mut *mut Bn254sProof) -> c_int;
     pub fn bn254s_prove_fq_exp(ctx: *mut Bn254sCtx, params: *const Bn254sParams, scalars: *const u64, x: *const u64,
                                n: usize, out: *mut *mut Bn254sProof) -> c_int;
+    /// idle slots give their (grow-only) device workspaces back to the driver
+    pub fn bn254s_ctx_trim(ctx: *mut Bn254sCtx) -> c_int;
+    /// hash_to_fq2 of n messages of `len` Goldilocks elements each, on the device: out[n][8]
+    pub fn bn254s_hash_to_fq2_batch(ctx: *mut Bn254sCtx, inputs: *const u64, n: usize, len: usize, out: *mut u64) -> c_int;
     pub fn bn254s_prove_batch(ctx: *mut Bn254sCtx, kind: c_int, params: *const Bn254sParams, scalars: *const u64,
                               x: *const u64, offset: *const u64, n_total: usize, per_proof: usize,
                               proofs: *mut *mut Bn254sProof) -> c_int;

@@ -184,6 +184,7 @@ def test_single_proof_calls_while_a_batch_is_open(gpu_ctx):
         b = gpu_ctx.prove_fq_exp(fs, fx)                    # and a different kind
         gpu_ctx.verify(0, a.words, 16, s[:5], x[:5], o[:5], a.outputs)
         h2 = gpu_ctx.prove_batch_begin(0, s[:256], x[:256], o[:256])
+        gpu_ctx.trim()                                      # idle slots give their workspaces back; running proofs are left alone
         c = gpu_ctx.prove_g1(s[128:256], x[128:256], o[128:256])
         got, got2 = h.end(), h2.end()
         assert np.array_equal(a.words, ref_single) and np.array_equal(b.words, ref_fq)
