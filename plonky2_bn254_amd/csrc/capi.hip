@@ -130,6 +130,17 @@ int bn254s_ctx_trim(bn254s_ctx* c) {
   } else {
     c->workers.for_idle_slots(give_back);
   }
+  // the context's own pool (buffers of the kernel-level entry points, cached point tables: rebuilt on demand) - only while no
+  // proof is queued or running, since running proofs hold pointers into it
+  bool idle;
+  {
+    std::lock_guard<std::mutex> lk(c->workers.mu);
+    idle = c->workers.n_busy == 0 && c->workers.q.empty();
+  }
+  if (idle) {
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->release();
+  }
   return BN254S_OK;
 }
 

@@ -18,6 +18,17 @@ void fri_openings(const u64* d_coeffs, size_t N, unsigned log_r, int npolys, con
 void fri_combine(const StarkShape& sh, const u64* d_tl, const u64* d_al, const u64* d_ql, const u64* d_apow, const u64* d_xs,
                  gl2 zeta, gl2 zeta_next, gl2 r0, gl2 r1, gl2 r2, gl2 alpha, size_t M2, u64* d_out, hipStream_t st);
 
+// The same from coefficient vectors (no resident LDE): comb[6][N] = the three alpha-weighted sums (f1, quotient part of f0, f2; c0 / c1
+// each) formed on the coefficients; after the ordinary LDE of those six columns fri_combine_final applies the point-wise part.
+void fri_combine_coeffs(const StarkShape& sh, const u64* d_tcoef, const u64* d_acoef, const u64* d_qcoef, const u64* d_apow, size_t N,
+                        u64* d_comb, hipStream_t st);
+void fri_combine_final(const StarkShape& sh, const u64* d_comb_lde, const u64* d_xs, gl2 zeta, gl2 zeta_next, gl2 r0, gl2 r1, gl2 r2,
+                       gl2 alpha, size_t M2, u64* d_out, hipStream_t st);
+// rows k0 .. k0 + rows - 1 (mod N) of coset h of ncols LDE columns (leaf order, column stride M2), natural order: out[ncols][rows]
+void fri_extract_window(const u64* d_lde, size_t M2, unsigned log_n, int h, size_t k0, size_t rows, int ncols, u64* d_out, hipStream_t st);
+// out[ncols][nq] = lde[c][indices[q]]
+void fri_gather_rows(const u64* d_lde, size_t M2, int ncols, const u32* d_indices, int nq, u64* d_out, hipStream_t st);
+
 void fri_fold(const u64* d_in, u64* d_out, unsigned log_m, u64 shift, gl2 beta, u64 inv16, hipStream_t st);
 
 void fri_pow_launch(const u64 state[12], int pos, u64 base, unsigned pow_bits, size_t count, unsigned long long* d_result,
@@ -26,6 +37,7 @@ void fri_pow_launch(const u64 state[12], int pos, u64 base, unsigned pow_bits, s
 static constexpr int FRI_MAX_LAYERS = 8;
 struct QueryGatherArgs {
   const u64* lde[3];
+  int lde_by_query[3] = {0, 0, 0};  // 1: lde[o] holds the leaf rows of the queries only, [width][n_queries] (fri_gather_rows)
   const u64* tree[3];
   int width[3];
   const u64* layer_vals[FRI_MAX_LAYERS];

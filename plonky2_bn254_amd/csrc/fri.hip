@@ -155,8 +155,63 @@ __global__ __launch_bounds__(256) void k_fri_combine(CombineArgs A) {
   reinterpret_cast<ulonglong2*>(A.out)[j] = make_ulonglong2(r.c0, r.c1);
 }
 
-void fri_combine(const StarkShape& sh, const u64* d_tl, const u64* d_al, const u64* d_ql, const u64* d_apow, const u64* d_xs,
-                 gl2 zeta, gl2 zeta_next, gl2 r0, gl2 r1, gl2 r2, gl2 alpha, size_t M2, u64* d_out, hipStream_t st) {
+// ---- the same batch polynomial from COEFFICIENTS (prover.hip "stream": no LDE of the commitments is resident) -----------------
+// The three alpha-weighted sums of k_fri_combine are linear in the polynomials, so they can be formed on the coefficient vectors
+// (all commitments share one coefficient layout): comb[0,1] = f1 (trace + aux), comb[2,3] = the quotient part of f0, comb[4,5]
+// = f2 (CTL Z columns), components c0 / c1.  The six columns then go through the ordinary LDE and k_fri_combine_final applies the
+// point-wise part.  Same field elements as k_fri_combine (sums of the same products).
+__global__ __launch_bounds__(256) void k_fri_combine_coeffs(CombineArgs A, u64* __restrict__ comb) {
+  const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= A.M2) return;
+  const size_t M2 = A.M2;  // (= N here: the arrays are coefficient vectors)
+  Acc3 g0, g1, z0, z1, q0, q1;
+  acc3_init(g0);
+  acc3_init(g1);
+  acc3_init(z0);
+  acc3_init(z1);
+  acc3_init(q0);
+  acc3_init(q1);
+  auto mad2 = [&](Acc3& a0, Acc3& a1, u64 v, const u32* e) {
+    const u32 v0 = (u32)v & M22, v1 = (u32)(v >> 22) & M22, v2 = (u32)(v >> 44);
+    acc3_mad(a0, v0, v1, v2, e[0], e[1], e[2]);
+    acc3_mad(a1, v0, v1, v2, e[4], e[5], e[6]);
+  };
+#pragma unroll 8
+  for (int c = 0; c < A.W; c++) mad2(g0, g1, A.tl[(size_t)c * M2 + j], A.apow3 + 8 * (size_t)c);
+  const u32* ap = A.apow3 + 8 * (size_t)A.W;
+#pragma unroll 8
+  for (int c = 0; c < A.num_lookup; c++) mad2(g0, g1, A.al[(size_t)c * M2 + j], ap + 8 * (size_t)c);
+  for (int c = A.num_lookup; c < A.A; c++) {
+    u64 v = A.al[(size_t)c * M2 + j];
+    mad2(g0, g1, v, ap + 8 * (size_t)c);
+    mad2(z0, z1, v, A.apow3 + 8 * (size_t)(c - A.num_lookup));
+  }
+  ap = A.apow3 + 8 * (size_t)(A.W + A.A);
+  for (int c = 0; c < 4; c++) mad2(q0, q1, A.ql[(size_t)c * M2 + j], ap + 8 * (size_t)c);
+  comb[0 * M2 + j] = acc3_red(g0);
+  comb[1 * M2 + j] = acc3_red(g1);
+  comb[2 * M2 + j] = acc3_red(q0);
+  comb[3 * M2 + j] = acc3_red(q1);
+  comb[4 * M2 + j] = acc3_red(z0);
+  comb[5 * M2 + j] = acc3_red(z1);
+}
+__global__ __launch_bounds__(256) void k_fri_combine_final(CombineArgs A, const u64* __restrict__ cl /* [6][M2] LDE of comb */) {
+  const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= A.M2) return;
+  const size_t M2 = A.M2;
+  const gl2 f1 = gl2_make(cl[0 * M2 + j], cl[1 * M2 + j]);
+  const gl2 f0 = gl2_add(f1, gl2_make(cl[2 * M2 + j], cl[3 * M2 + j]));
+  const gl2 f2 = gl2_make(cl[4 * M2 + j], cl[5 * M2 + j]);
+  const u64 x = A.xs[j];
+  gl2 xe = gl2_make(x, 0);
+  gl2 t0 = gl2_mul(gl2_sub(f0, A.r0), gl2_inv(gl2_sub(xe, A.zeta)));
+  gl2 t1 = gl2_mul(gl2_sub(f1, A.r1), gl2_inv(gl2_sub(xe, A.zeta_next)));
+  gl2 t2 = gl2_mul_base(gl2_sub(f2, A.r2), gl_inv(gl_sub(x, 1)));
+  gl2 r = gl2_add(gl2_add(gl2_mul(t0, A.a_n1n2), gl2_mul(t1, A.a_n2)), t2);
+  reinterpret_cast<ulonglong2*>(A.out)[j] = make_ulonglong2(r.c0, r.c1);
+}
+static CombineArgs combine_args(const StarkShape& sh, const u64* d_tl, const u64* d_al, const u64* d_ql, const u64* d_apow, const u64* d_xs,
+                                gl2 zeta, gl2 zeta_next, gl2 r0, gl2 r1, gl2 r2, gl2 alpha, size_t M2, u64* d_out) {
   CombineArgs A;
   A.tl = d_tl;
   A.al = d_al;
@@ -176,6 +231,45 @@ void fri_combine(const StarkShape& sh, const u64* d_tl, const u64* d_al, const u
   A.a_n1n2 = gl2_pow(alpha, n1 + n2);
   A.out = d_out;
   A.M2 = M2;
+  return A;
+}
+void fri_combine_coeffs(const StarkShape& sh, const u64* d_tcoef, const u64* d_acoef, const u64* d_qcoef, const u64* d_apow, size_t N,
+                        u64* d_comb, hipStream_t st) {
+  const gl2 z = gl2_make(0, 0);
+  CombineArgs A = combine_args(sh, d_tcoef, d_acoef, d_qcoef, d_apow, nullptr, z, z, z, z, z, gl2_make(1, 0), N, nullptr);
+  k_fri_combine_coeffs<<<(unsigned)((N + 255) / 256), 256, 0, st>>>(A, d_comb);
+}
+void fri_combine_final(const StarkShape& sh, const u64* d_comb_lde, const u64* d_xs, gl2 zeta, gl2 zeta_next, gl2 r0, gl2 r1, gl2 r2,
+                       gl2 alpha, size_t M2, u64* d_out, hipStream_t st) {
+  CombineArgs A = combine_args(sh, nullptr, nullptr, nullptr, nullptr, d_xs, zeta, zeta_next, r0, r1, r2, alpha, M2, d_out);
+  k_fri_combine_final<<<(unsigned)((M2 + 255) / 256), 256, 0, st>>>(A, d_comb_lde);
+}
+
+// rows k0 .. k0 + rows - 1 (mod N) of coset h of `ncols` LDE columns (leaf order, stride M2) in natural order: out[c][t]
+__global__ __launch_bounds__(256) void k_extract_window(const u64* __restrict__ lde, size_t M2, unsigned log_n, u32 h, size_t k0,
+                                                        size_t rows, u64* __restrict__ out) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= rows) return;
+  const size_t N = (size_t)1 << log_n;
+  const u32 k = (u32)((k0 + t) & (N - 1));
+  out[(size_t)blockIdx.y * rows + t] = lde[(size_t)blockIdx.y * M2 + ((size_t)h << log_n) + bitrev32(k, log_n)];
+}
+void fri_extract_window(const u64* d_lde, size_t M2, unsigned log_n, int h, size_t k0, size_t rows, int ncols, u64* d_out, hipStream_t st) {
+  k_extract_window<<<dim3((unsigned)((rows + 255) / 256), ncols), 256, 0, st>>>(d_lde, M2, log_n, (u32)h, k0, rows, d_out);
+}
+// out[c][q] = lde[c][indices[q]]: the leaf rows of the queries of `ncols` columns
+__global__ void k_gather_rows(const u64* __restrict__ lde, size_t M2, const u32* __restrict__ indices, int nq, u64* __restrict__ out) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= nq) return;
+  out[(size_t)blockIdx.y * nq + q] = lde[(size_t)blockIdx.y * M2 + indices[q]];
+}
+void fri_gather_rows(const u64* d_lde, size_t M2, int ncols, const u32* d_indices, int nq, u64* d_out, hipStream_t st) {
+  k_gather_rows<<<dim3((unsigned)((nq + 63) / 64), ncols), 64, 0, st>>>(d_lde, M2, d_indices, nq, d_out);
+}
+
+void fri_combine(const StarkShape& sh, const u64* d_tl, const u64* d_al, const u64* d_ql, const u64* d_apow, const u64* d_xs,
+                 gl2 zeta, gl2 zeta_next, gl2 r0, gl2 r1, gl2 r2, gl2 alpha, size_t M2, u64* d_out, hipStream_t st) {
+  CombineArgs A = combine_args(sh, d_tl, d_al, d_ql, d_apow, d_xs, zeta, zeta_next, r0, r1, r2, alpha, M2, d_out);
   k_fri_combine<<<(unsigned)((M2 + 255) / 256), 256, 0, st>>>(A);
 }
 
@@ -285,7 +379,11 @@ __global__ __launch_bounds__(256) void k_gather_queries(QueryGatherArgs A) {
   for (int o = 0; o < 3; o++) {
     const u64* lde = A.lde[o];
     const int width = A.width[o];
-    for (int c = t; c < width; c += blockDim.x) out[c] = lde[(size_t)c * A.M2 + x_index];
+    if (A.lde_by_query[o]) {  // leaf rows gathered beforehand: [width][n_queries]
+      for (int c = t; c < width; c += blockDim.x) out[c] = lde[(size_t)c * gridDim.x + q];
+    } else {
+      for (int c = t; c < width; c += blockDim.x) out[c] = lde[(size_t)c * A.M2 + x_index];
+    }
     out += width;
     // Merkle path: sibling at each level
     const int plen = A.log_m2 - A.cap_height;

@@ -137,6 +137,39 @@ void merkle_leaves(const u64* data, size_t leaf_stride, size_t elem_stride, int 
   }
 }
 
+// ---- streaming commitment (prover.hip "stream": the LDE of a commitment never exists as a whole) --------------------------------
+// hash_no_pad over the columns of a leaf, a chunk of columns at a time: the sponge states of all leaves stay resident between
+// chunks (state lane l of leaf j at state[l * n_leaves + j]); a chunk brings `ncols` columns (a multiple of the rate 8, except for
+// the last chunk of a commitment), each absorbed block is overwritten into lanes 0.. and permuted, exactly the sequence
+// hash_no_pad runs.  `first`: start from the zero state; digests != nullptr (last chunk): write the digest instead of the state.
+__global__ __launch_bounds__(256) void k_leaf_absorb(const u64* __restrict__ data, size_t elem_stride, int ncols, size_t n_leaves,
+                                                     u64* __restrict__ state, int first, u64* __restrict__ digests) {
+  const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n_leaves) return;
+  u64 s[12];
+#pragma unroll
+  for (int l = 0; l < 12; l++) s[l] = first ? 0 : state[(size_t)l * n_leaves + j];
+#pragma unroll 1
+  for (int c = 0; c < ncols; c += 8) {
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+      if (c + i < ncols) s[i] = data[(size_t)(c + i) * elem_stride + j];
+    poseidon_permute(s);
+  }
+  if (digests) {
+    ulonglong2* o = reinterpret_cast<ulonglong2*>(digests + 4 * j);
+    o[0] = make_ulonglong2(s[0], s[1]);
+    o[1] = make_ulonglong2(s[2], s[3]);
+  } else {
+#pragma unroll
+    for (int l = 0; l < 12; l++) state[(size_t)l * n_leaves + j] = s[l];
+  }
+}
+void merkle_absorb(const u64* data, size_t elem_stride, int ncols, int log_leaves, u64* state, bool first, u64* digests, hipStream_t s) {
+  const size_t n = (size_t)1 << log_leaves;
+  k_leaf_absorb<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(data, elem_stride, ncols, n, state, first ? 1 : 0, digests);
+}
+
 void merkle_upper(int log_leaves, int cap_height, u64* tree, hipStream_t s) {
   for (int l = 0; l < log_leaves - cap_height; l++) {
     size_t n_out = (size_t)1 << (log_leaves - l - 1);

@@ -194,7 +194,22 @@ static int prove_on_slot(bn254s_ctx* c, Slot& sl, int kind, const bn254s_params&
   // compact).  BN254S_FORCE_LOWMEM=1 selects it for any tall proof (tests).
   const bool force_lowmem = getenv("BN254S_FORCE_LOWMEM") && atoi(getenv("BN254S_FORCE_LOWMEM"));
   const double plain_bytes = 8.0 * (double)N * (4.0 * sh.W + 4.0 * sh.n_aux() + std::max(sh.W, sh.n_aux()));
-  const bool lowmem = log_s || (log_n > 16 && (force_lowmem || plain_bytes > 200e9));
+  // "stream": even the compact workspace does not fit (G2 at 2^23 rows: its two LDEs alone are 296 GB).  Only the coefficients
+  // stay resident; a commitment streams 16-column chunks through the NTT into a leaf hash that absorbs into resident sponge
+  // states, and wherever LDE rows are needed they are recomputed from the coefficients: the quotient runs over windows of
+  // consecutive rows of a coset (natural order, QArgs window mode), the FRI batch polynomial is formed on the coefficient
+  // vectors (it is linear in them) and extended once, the query rows are gathered from one more pass of chunk LDEs.
+  // BN254S_FORCE_STREAM=1 takes this path for any proof above 2^16 rows (tests: word for word against the oracle at 2^17 / 2^18);
+  // BN254S_STREAM_WIN_LOG = log2 of the rows per window (default: at most 2^22, at least two windows per coset).
+  const bool force_stream = getenv("BN254S_FORCE_STREAM") && atoi(getenv("BN254S_FORCE_STREAM"));
+  const double compact_bytes = 8.0 * ((double)std::max((size_t)sh.W * N, (size_t)sh.n_aux() * 2 * N) + (double)sh.W * N * 3.0 + (double)sh.n_aux() * N);
+  size_t dev_free_b = 0, dev_total_b = 0;
+  (void)hipMemGetInfo(&dev_free_b, &dev_total_b);
+  const bool stream = log_n > 16 && (force_stream || (dev_total_b > 0 && compact_bytes + 20e9 > (double)dev_total_b));
+  const bool lowmem = stream || log_s || (log_n > 16 && (force_lowmem || plain_bytes > 200e9));
+  unsigned log_bk = std::min(22u, log_n - 1);
+  if (const char* e = getenv("BN254S_STREAM_WIN_LOG")) log_bk = std::min(log_n, std::max(8u, (unsigned)atoi(e)));
+  const size_t BK = (size_t)1 << log_bk, WROWS = BK + 1;  // rows per quotient window (+ the next row of the last one)
   const int W = sh.W, A = sh.n_aux(), NQ = 4, CAPW = 64;
   const int K = sh.n_total_constraints();
   hipStream_t st = sl.st;
@@ -258,6 +273,36 @@ static int prove_on_slot(bn254s_ctx* c, Slot& sl, int kind, const bn254s_params&
     } else if (log_r) ntt_lde_tall(&c->ntt, TT, coef, lde, d_tmp_fwd, nc, st);
     else ntt_lde(&c->ntt, coef, lde, d_tmp_fwd, nc, st);
   };
+  // stream mode: the LDE of ONE column chunk (coefficients at `coef`, cn <= CH columns) into d_ldechunk
+  u64* d_ldechunk_fwd = nullptr;  // (= d_ldechunk once the workspace is set up)
+  auto lde_chunk = [&](const u64* coef, int cn) {
+    if (log_s) {
+      u64* eo = d_tmp_fwd;
+      u64* ntmp = d_tmp_fwd + (size_t)CH * 2 * N;
+      ntt_lde_tall(&c->ntt, TT, coef, eo, ntmp, 2 * cn, st);
+      ntt_split_forward(SP, eo, d_ldechunk_fwd, M2, cn, st);
+    } else {
+      ntt_lde_tall(&c->ntt, TT, coef, d_ldechunk_fwd, d_tmp_fwd, cn, st);
+    }
+  };
+  // stream mode: from_values of a commitment, chunk by chunk: coefficients stay, the chunk's LDE is absorbed by the leaf hash
+  u64* d_sponge_fwd = nullptr;
+  const unsigned log_m2_fwd = log_n + 1;
+  auto commit_stream = [&](const u64* vals, u64* coef, int nc, u64* tree) {
+    for (int c0 = 0; c0 < nc; c0 += CH) {
+      const int cn = std::min(CH, nc - c0);
+      if (log_s) {
+        u64* eo = d_tmp_fwd;
+        u64* ntmp = d_tmp_fwd + (size_t)CH * 2 * N;
+        ntt_split_inverse(SP, vals + (size_t)c0 * N, coef + (size_t)c0 * N, cn, st);
+        ntt_inverse_lde_tall(&c->ntt, TT, coef + (size_t)c0 * N, coef + (size_t)c0 * N, eo, ntmp, 2 * cn, st);
+        ntt_split_forward(SP, eo, d_ldechunk_fwd, M2, cn, st);
+      } else {
+        ntt_inverse_lde_tall(&c->ntt, TT, vals + (size_t)c0 * N, coef + (size_t)c0 * N, d_ldechunk_fwd, d_tmp_fwd, cn, st);
+      }
+      merkle_absorb(d_ldechunk_fwd, M2, cn, (int)log_m2_fwd, d_sponge_fwd, c0 == 0, c0 + cn == nc ? tree : nullptr, st);
+    }
+  };
   const std::vector<int> arities = fri_arities(P, log_n);
   const int L = (int)arities.size();
   if (L > FRI_MAX_LAYERS) return BN254S_E_UNSUPPORTED;
@@ -270,21 +315,34 @@ static int prove_on_slot(bn254s_ctx* c, Slot& sl, int kind, const bn254s_params&
   }
   u64* d_in = mem.words("in", in_words + 16);
   // compact workspace: the trace values are dead once the auxiliary values exist, the auxiliary LDE takes their place
-  u64* d_tvals = mem.words("tvals", lowmem ? std::max((size_t)W * N, (size_t)A * M2) : (size_t)W * N);
+  u64* d_tvals = mem.words("tvals", lowmem && !stream ? std::max((size_t)W * N, (size_t)A * M2) : (size_t)W * N);
   u64* d_tcoef = mem.words("tcoef", (size_t)W * N);
   u64* d_hist = mem.words("hist", 65536 / 2);
   // [tmp | y0 | y1] for the fused commitment; one tmp for a tall one; [E,O LDEs | tmp] of one column chunk under the split level
   u64* d_tmp = mem.words("tmp", log_s ? (size_t)3 * CH * N : lowmem ? (size_t)CH * N : (size_t)(log_r ? 1 : 3) * std::max(W, A) * N);
   d_tmp_fwd = d_tmp;
-  u64* d_tlde = mem.words("tlde", (size_t)W * M2);
+  mem.drop("win");  // (allocated in the middle of a streaming proof, in the memory of its dead trace values)
+  if (stream) {  // no resident LDE: whatever an earlier proof left in the slot under these names goes first
+    mem.drop("tlde");
+    mem.drop("alde");
+    mem.drop("acoef");
+  } else {
+    mem.drop("ldechunk");
+    mem.drop("sponge");
+    mem.drop("comb");
+  }
+  u64* d_ldechunk = stream ? mem.words("ldechunk", (size_t)CH * M2) : nullptr;  // the LDE of one column chunk
+  u64* d_sponge = stream ? mem.words("sponge", (size_t)12 * M2) : nullptr;      // sponge states of the streaming leaf hash
+  u64* d_comb = stream ? mem.words("comb", (size_t)6 * N + (size_t)6 * M2) : nullptr;  // FRI batch polynomial: coefficients | LDE
+  u64* d_tlde = stream ? d_ldechunk : mem.words("tlde", (size_t)W * M2);
   const size_t tree_words = merkle_tree_digests(log_m2, P.cap_height) * 4;
   u64* d_trees = mem.words("trees", 3 * tree_words);
   u64* d_avals = mem.words("avals", (size_t)A * N);
   u64* d_acoef = lowmem ? d_avals : mem.words("acoef", (size_t)A * N);         // compact workspace: the commitment runs in place
-  u64* d_alde = lowmem ? d_tvals : mem.words("alde", (size_t)A * M2);
+  u64* d_alde = stream ? d_ldechunk : lowmem ? d_tvals : mem.words("alde", (size_t)A * M2);
   const size_t trace_scr = kind == KIND_G1 ? g1_trace_scratch_words(n) : kind == KIND_G2 ? g2_trace_scratch_words(n) : fq_trace_scratch_words(n);
   u64* d_scr = mem.words("scratch", std::max(trace_scr, aux_scratch_words(sh, N)));
-  u64* d_q = mem.words("quot", (size_t)(3 * NQ) * N + (size_t)NQ * M2 + (size_t)QUOTIENT_MAX_PARTS * 2 * M2);  // qv, ab, qcoef, qlde, partials
+  u64* d_q = mem.words("quot", (size_t)(3 * NQ) * N + (size_t)NQ * M2 + (size_t)QUOTIENT_MAX_PARTS * 2 * (stream ? WROWS : M2));  // qv, ab, qcoef, qlde, partials
   u64* d_tabs = mem.words("tabs", 2 * (size_t)K + 10 * 2 * 80 + 4 * (size_t)(W + A + NQ));  // W, mzt, apow (8 u32 per power)
   u64* d_open = mem.words("open", std::max((size_t)(W + A + NQ) * NSPL * R * 5 + FRI_OPENING_TABLE_WORDS, n * (size_t)PW));
   // FRI layer values (extension, 2 words) and trees
@@ -320,7 +378,7 @@ static int prove_on_slot(bn254s_ctx* c, Slot& sl, int kind, const bn254s_params&
     }
   }
   if (!d_hist || !d_in || !d_tvals || !d_tcoef || !d_tmp || !d_tlde || !d_trees || !d_avals || !d_acoef || !d_alde || !d_scr || !d_q ||
-      !d_tabs || !d_open || !d_fri || !d_fritrees || !d_qout) {
+      !d_tabs || !d_open || !d_fri || !d_fritrees || !d_qout || (stream && (!d_ldechunk || !d_sponge || !d_comb))) {
     err = mem.err;
     mem.release();  // a workspace that could not be completed is given back: the context stays usable for smaller proofs
     return BN254S_E_OOM;
@@ -340,6 +398,8 @@ static int prove_on_slot(bn254s_ctx* c, Slot& sl, int kind, const bn254s_params&
     }
   }
   if (after_alloc) (*after_alloc)();
+  d_ldechunk_fwd = d_ldechunk;
+  d_sponge_fwd = d_sponge;
   int* d_err = (int*)(d_in + in_words);
   unsigned long long* d_pow = (unsigned long long*)(d_in + in_words + 2);
   u32* d_qidx = (u32*)(d_qout + wpq * P.num_queries);
@@ -397,16 +457,24 @@ static int prove_on_slot(bn254s_ctx* c, Slot& sl, int kind, const bn254s_params&
   se(ST_TRACE);
 
   // ---- trace commitment (prover.rs:31-38) -----------------------------------------------------------------
-  {
+  if (stream) {  // (the NTT and the leaf hash alternate chunk by chunk: one section, timed as the NTT stage)
     BigSection big(c, st, BIG_NTT);
     sb(ST_TRACE_NTT);
-    do_commit_ntt(d_tvals, d_tcoef, d_tlde, W);
+    commit_stream(d_tvals, d_tcoef, W, d_ttree);
     se(ST_TRACE_NTT);
-  }
-  {
-    BigSection big(c, st, BIG_HASH);
     sb(ST_TRACE_MERKLE);
-    merkle_leaves(d_tlde, 1, M2, W, log_m2, d_ttree, st);
+  } else {
+    {
+      BigSection big(c, st, BIG_NTT);
+      sb(ST_TRACE_NTT);
+      do_commit_ntt(d_tvals, d_tcoef, d_tlde, W);
+      se(ST_TRACE_NTT);
+    }
+    {
+      BigSection big(c, st, BIG_HASH);
+      sb(ST_TRACE_MERKLE);
+      merkle_leaves(d_tlde, 1, M2, W, log_m2, d_ttree, st);
+    }
   }
   merkle_upper(log_m2, P.cap_height, d_ttree, st);
   u64 caps[3][64];
@@ -437,16 +505,40 @@ static int prove_on_slot(bn254s_ctx* c, Slot& sl, int kind, const bn254s_params&
     aux_build(sh, d_tvals, N, betas, gammas, d_avals, d_scr, d_err, st);
     se(ST_AUX);
   }
-  {
+  u64 *d_tw = nullptr, *d_aw = nullptr, *d_wpt = nullptr, *d_qrows = nullptr;
+  if (stream) {
+    // the trace values are dead: their memory becomes the quotient windows (all columns x WROWS rows), the window's point tables
+    // and the leaf rows of the queries
+    CHK(hipStreamSynchronize(st));
+    mem.drop("tvals");
+    d_tvals = nullptr;
+    u64* win = mem.words("win", (size_t)(W + A) * WROWS + 3 * WROWS + (size_t)(W + A) * P.num_queries);
+    if (!win) {
+      err = mem.err;
+      mem.release();
+      return BN254S_E_OOM;
+    }
+    d_tw = win;
+    d_aw = win + (size_t)W * WROWS;
+    d_wpt = d_aw + (size_t)A * WROWS;
+    d_qrows = d_wpt + 3 * WROWS;
     BigSection big(c, st, BIG_NTT);
     sb(ST_AUX_NTT);
-    do_commit_ntt(d_avals, d_acoef, d_alde, A);
+    commit_stream(d_avals, d_acoef, A, d_atree);
     se(ST_AUX_NTT);
-  }
-  {
-    BigSection big(c, st, BIG_HASH);
     sb(ST_AUX_MERKLE);
-    merkle_leaves(d_alde, 1, M2, A, log_m2, d_atree, st);
+  } else {
+    {
+      BigSection big(c, st, BIG_NTT);
+      sb(ST_AUX_NTT);
+      do_commit_ntt(d_avals, d_acoef, d_alde, A);
+      se(ST_AUX_NTT);
+    }
+    {
+      BigSection big(c, st, BIG_HASH);
+      sb(ST_AUX_MERKLE);
+      merkle_leaves(d_alde, 1, M2, A, log_m2, d_atree, st);
+    }
   }
   merkle_upper(log_m2, P.cap_height, d_atree, st);
   CHK(hipMemcpyAsync(caps[1], d_atree + cap_off, CAPW * 8, hipMemcpyDeviceToHost, st));
@@ -466,7 +558,36 @@ static int prove_on_slot(bn254s_ctx* c, Slot& sl, int kind, const bn254s_params&
     CHK(hipMemcpyAsync(d_mzt, hmzt.data(), hmzt.size() * 8, hipMemcpyHostToDevice, st));
     CHK(hipStreamSynchronize(st));  // host vectors go out of scope
   }
-  {
+  if (stream) {
+    // per coset and window of BK consecutive rows: the LDE of every column chunk is recomputed and the window's rows (plus the next
+    // one) are taken out in natural order; the quotient kernels then run on the window (QArgs window mode)
+    BigSection big(c, st, BIG_NTT);
+    sb(ST_QUOTIENT);
+    QPointTables wpt;
+    wpt.x = d_wpt;
+    wpt.lfirst = d_wpt + WROWS;
+    wpt.llast = d_wpt + 2 * WROWS;
+    for (int h = 0; h < 2; h++)
+      for (size_t k0 = 0; k0 < N; k0 += BK) {
+        for (int c0 = 0; c0 < W; c0 += CH) {
+          const int cn = std::min(CH, W - c0);
+          lde_chunk(d_tcoef + (size_t)c0 * N, cn);
+          fri_extract_window(d_ldechunk, M2, log_n, h, k0, WROWS, cn, d_tw + (size_t)c0 * WROWS, st);
+        }
+        for (int c0 = 0; c0 < A; c0 += CH) {
+          const int cn = std::min(CH, A - c0);
+          lde_chunk(d_acoef + (size_t)c0 * N, cn);
+          fri_extract_window(d_ldechunk, M2, log_n, h, k0, WROWS, cn, d_aw + (size_t)c0 * WROWS, st);
+        }
+        quotient_point_tables_window(d_wpt, d_wpt + WROWS, d_wpt + 2 * WROWS, log_n, h, k0, WROWS, st);
+        QArgs QA;
+        quotient_fill_args(QA, sh, nullptr, nullptr, d_W, d_mzt, pt, betas, gammas, log_n, d_qv, d_qpart);
+        quotient_window_args(QA, d_tw, d_aw, wpt, d_qpart, WROWS, BK, k0, h);
+        if (kind == KIND_G1) g1_quotient_launch(QA, sh, st);
+        else if (kind == KIND_G2) g2_quotient_launch(QA, sh, st);
+        else fq_quotient_launch(QA, sh, st);
+      }
+  } else {
     BigSection big(c, st, BIG_EXCL);
     sb(ST_QUOTIENT);
     QArgs QA;
@@ -589,7 +710,13 @@ static int prove_on_slot(bn254s_ctx* c, Slot& sl, int kind, const bn254s_params&
     CHK(hipStreamSynchronize(st));
     BigSection big(c, st, BIG_EXCL);
     sb(ST_FRI);
-    fri_combine(sh, d_tlde, d_alde, d_qlde, d_apow, pt.x, zeta, zeta_next, r0, r1, r2, fri_alpha, M2, d_fri, st);
+    if (stream) {  // the batch polynomial on the coefficient vectors, one LDE of its six columns, then the point-wise part
+      fri_combine_coeffs(sh, d_tcoef, d_acoef, d_qcoef, d_apow, N, d_comb, st);
+      do_lde(d_comb, d_comb + (size_t)6 * N, 6);
+      fri_combine_final(sh, d_comb + (size_t)6 * N, pt.x, zeta, zeta_next, r0, r1, r2, fri_alpha, M2, d_fri, st);
+    } else {
+      fri_combine(sh, d_tlde, d_alde, d_qlde, d_apow, pt.x, zeta, zeta_next, r0, r1, r2, fri_alpha, M2, d_fri, st);
+    }
   }
   std::vector<std::vector<u64>> layer_caps(L, std::vector<u64>(CAPW));
   std::vector<const u64*> layer_vals(L), layer_trees(L);
@@ -676,9 +803,27 @@ static int prove_on_slot(bn254s_ctx* c, Slot& sl, int kind, const bn254s_params&
   std::vector<u32> qidx(P.num_queries);
   for (auto& q : qidx) q = (u32)(ch.challenge() % M2);
   CHK(hipMemcpyAsync(d_qidx, qidx.data(), qidx.size() * 4, hipMemcpyHostToDevice, st));
+  if (stream) {  // leaf rows of the queries: one more pass of chunk LDEs, 84 rows taken out of each
+    const int nq = (int)P.num_queries;
+    for (int c0 = 0; c0 < W; c0 += CH) {
+      const int cn = std::min(CH, W - c0);
+      lde_chunk(d_tcoef + (size_t)c0 * N, cn);
+      fri_gather_rows(d_ldechunk, M2, cn, d_qidx, nq, d_qrows + (size_t)c0 * nq, st);
+    }
+    for (int c0 = 0; c0 < A; c0 += CH) {
+      const int cn = std::min(CH, A - c0);
+      lde_chunk(d_acoef + (size_t)c0 * N, cn);
+      fri_gather_rows(d_ldechunk, M2, cn, d_qidx, nq, d_qrows + (size_t)(W + c0) * nq, st);
+    }
+  }
   {
     QueryGatherArgs G;
     G.lde[0] = d_tlde; G.lde[1] = d_alde; G.lde[2] = d_qlde;
+    if (stream) {
+      G.lde[0] = d_qrows;
+      G.lde[1] = d_qrows + (size_t)W * P.num_queries;
+      G.lde_by_query[0] = G.lde_by_query[1] = 1;
+    }
     G.tree[0] = d_ttree; G.tree[1] = d_atree; G.tree[2] = d_qtree;
     G.width[0] = W; G.width[1] = A; G.width[2] = NQ;
     for (int l = 0; l < L; l++) {

@@ -23,16 +23,15 @@ static constexpr int G1_MZ_E0[5] = {0, 50, 83, 132, 165};
 // part 5: the schedule.  One lane per LDE point and part, one launch per part.
 __global__ __launch_bounds__(256) void k_quotient_g1_sched(QArgs A) {
   const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= ((size_t)2 << A.log_n)) return;
-  schedule_part<G1L, false>(A, j, next_position(j, A.log_n), 198, 5);
+  if (j >= A.count) return;
+  schedule_part<G1L, false>(A, j, q_next(A, j), 198, 5);
 }
 
 template <int part>
 __global__ __launch_bounds__(256, 2) void k_quotient_g1_add(QArgs A) {
-  const unsigned log_n = A.log_n;
-  const size_t N = (size_t)1 << log_n, M2 = 2 * N;
+  const size_t M2 = A.stride;
   const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= M2) return;
+  if (j >= A.count) return;
   const u64* __restrict__ tl = A.tl;
   const u64* __restrict__ W0 = A.W;
   const u64* __restrict__ W1 = A.W + A.K;
@@ -128,12 +127,11 @@ __global__ __launch_bounds__(256, 2) void k_quotient_g1_add(QArgs A) {
 
 __global__ __launch_bounds__(256) void k_quotient_finish(QArgs A, StarkShape sh) {
   const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= ((size_t)2 << A.log_n)) return;
+  if (j >= A.count) return;
   finish_point(A, sh, j);
 }
 void quotient_finish_launch(const QArgs& A, const StarkShape& sh, hipStream_t st) {
-  size_t M2 = (size_t)2 << A.log_n;
-  k_quotient_finish<<<(unsigned)((M2 + 255) / 256), 256, 0, st>>>(A, sh);
+  k_quotient_finish<<<(unsigned)((A.count + 255) / 256), 256, 0, st>>>(A, sh);
 }
 
 // ---- per-context point tables ---------------------------------------------------------------------------------
@@ -152,6 +150,40 @@ __global__ void k_point_tables(u64* x, u64* lfirst, u64* llast, unsigned log_n, 
   x[j] = xv;
   lfirst[j] = gl_mul(gl_mul(zh, ninv), gl_inv(gl_sub(xv, 1)));
   llast[j] = gl_mul(gl_mul(gl_mul(zh, ninv), winv), gl_inv(gl_sub(xv, winv)));
+}
+
+// the same constants for `count` consecutive rows k0 .. of coset h in natural order (window mode of QArgs)
+__global__ void k_point_tables_window(u64* x, u64* lfirst, u64* llast, unsigned log_n, u32 h, size_t k0, size_t count, u64 w_n,
+                                      u64 w_2n) {
+  const size_t N = (size_t)1 << log_n;
+  size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= count) return;
+  const u64 k = (k0 + j) & (N - 1);
+  u64 shift = h ? gl_mul(GL_GEN, w_2n) : GL_GEN;
+  u64 xv = gl_mul(shift, gl_pow(w_n, k));
+  u64 gn = gl_pow(GL_GEN, N);
+  u64 zh = gl_sub(h ? gl_neg(gn) : gn, 1);
+  u64 ninv = gl_inv((u64)N % GL_P);
+  u64 winv = gl_inv(w_n);
+  x[j] = xv;
+  lfirst[j] = gl_mul(gl_mul(zh, ninv), gl_inv(gl_sub(xv, 1)));
+  llast[j] = gl_mul(gl_mul(gl_mul(zh, ninv), winv), gl_inv(gl_sub(xv, winv)));
+}
+void quotient_point_tables_window(u64* d_x, u64* d_lfirst, u64* d_llast, unsigned log_n, int h, size_t k0, size_t count, hipStream_t st) {
+  k_point_tables_window<<<(unsigned)((count + 255) / 256), 256, 0, st>>>(d_x, d_lfirst, d_llast, log_n, (u32)h, k0, count,
+                                                                       gl_root_of_unity(log_n), gl_root_of_unity(log_n + 1));
+}
+void quotient_window_args(QArgs& A, const u64* d_tw, const u64* d_aw, const QPointTables& pt, u64* d_part, size_t stride, size_t count,
+                          size_t k0, int h) {
+  A.tl = d_tw;
+  A.al = d_aw;
+  A.pt = pt;
+  A.part = d_part;
+  A.stride = stride;
+  A.count = count;
+  A.k0 = k0;
+  A.natural = 1;
+  A.hsel = (u32)h;
 }
 
 void quotient_point_tables(u64* d_x, u64* d_lfirst, u64* d_llast, unsigned log_n, hipStream_t st) {
@@ -217,6 +249,10 @@ void quotient_fill_args(QArgs& A, const StarkShape& sh, const u64* d_tl, const u
   A.n_parts = 0;
   A.log_n = log_n;
   A.K = sh.n_total_constraints();
+  A.stride = A.count = 2 * N;  // the whole LDE domain in leaf order; quotient_window_args() narrows it
+  A.k0 = 0;
+  A.natural = 0;
+  A.hsel = 0;
 }
 
 int g1_quotient_mz_blocks(const int** e0) {
@@ -226,8 +262,7 @@ int g1_quotient_mz_blocks(const int** e0) {
 void g1_quotient_launch(const QArgs& A0, const StarkShape& sh, hipStream_t st) {
   QArgs A = A0;
   A.n_parts = 6;
-  size_t M2 = (size_t)2 << A.log_n;
-  const unsigned g = (unsigned)((M2 + 255) / 256);
+  const unsigned g = (unsigned)((A.count + 255) / 256);
   k_quotient_g1_add<0><<<g, 256, 0, st>>>(A);
   k_quotient_g1_add<1><<<g, 256, 0, st>>>(A);
   k_quotient_g1_add<2><<<g, 256, 0, st>>>(A);

@@ -25,18 +25,17 @@ __device__ __forceinline__ u64 econv_c1(const u64* x0, const u64* x1, const u64*
 
 __global__ __launch_bounds__(256) void k_quotient_g2_sched(QArgs A) {
   const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= ((size_t)2 << A.log_n)) return;
-  schedule_part<G2L, false>(A, j, next_position(j, A.log_n), 396, 5);
+  if (j >= A.count) return;
+  schedule_part<G2L, false>(A, j, q_next(A, j), 396, 5);
 }
 
 // Parts 0..4 of eval_g2_add: {is-zero witnesses of delta_x, lambda (x !=), lambda (x ==) + a.y == b.y, x, y}.
 template <int part>
 __global__ __launch_bounds__(256, 2) void k_quotient_g2_add(QArgs A) {
   typedef G2L L;
-  const unsigned log_n = A.log_n;
-  const size_t N = (size_t)1 << log_n, M2 = 2 * N;
+  const size_t M2 = A.stride;
   const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= M2) return;
+  if (j >= A.count) return;
   const u64* __restrict__ tl = A.tl;
   const u64* __restrict__ W0 = A.W;
   const u64* __restrict__ W1 = A.W + A.K;
@@ -171,14 +170,14 @@ __global__ __launch_bounds__(256, 2) void k_quotient_g2_add(QArgs A) {
 
 __global__ __launch_bounds__(256) void k_quotient_fq_sched(QArgs A) {
   const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= ((size_t)2 << A.log_n)) return;
-  schedule_part<FQL, true>(A, j, next_position(j, A.log_n), 33, 1);
+  if (j >= A.count) return;
+  schedule_part<FQL, true>(A, j, q_next(A, j), 33, 1);
 }
 __global__ __launch_bounds__(256) void k_quotient_fq_mul(QArgs A) {
   typedef FQL L;
-  const size_t M2 = (size_t)2 << A.log_n;
+  const size_t M2 = A.stride;
   const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= M2) return;
+  if (j >= A.count) return;
   const u64* __restrict__ tl = A.tl;
   const u64* __restrict__ W0 = A.W;
   const u64* __restrict__ W1 = A.W + A.K;
@@ -209,7 +208,7 @@ int fq_quotient_mz_blocks(const int** e0) {
 void g2_quotient_launch(const QArgs& A0, const StarkShape& sh, hipStream_t st) {
   QArgs A = A0;
   A.n_parts = 6;
-  const unsigned g = (unsigned)((((size_t)2 << A.log_n) + 255) / 256);
+  const unsigned g = (unsigned)((A.count + 255) / 256);
   k_quotient_g2_add<0><<<g, 256, 0, st>>>(A);
   k_quotient_g2_add<1><<<g, 256, 0, st>>>(A);
   k_quotient_g2_add<2><<<g, 256, 0, st>>>(A);
@@ -221,7 +220,7 @@ void g2_quotient_launch(const QArgs& A0, const StarkShape& sh, hipStream_t st) {
 void fq_quotient_launch(const QArgs& A0, const StarkShape& sh, hipStream_t st) {
   QArgs A = A0;
   A.n_parts = 2;
-  const unsigned g = (unsigned)((((size_t)2 << A.log_n) + 255) / 256);
+  const unsigned g = (unsigned)((A.count + 255) / 256);
   k_quotient_fq_mul<<<g, 256, 0, st>>>(A);
   k_quotient_fq_sched<<<g, 256, 0, st>>>(A);
   quotient_finish_launch(A, sh, st);

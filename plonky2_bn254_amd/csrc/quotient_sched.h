@@ -27,7 +27,14 @@ struct QArgs {
   int n_parts;
   unsigned log_n;
   int K;
+  // Which points a launch covers.  Whole domain (default): count = stride = 2N, point j is leaf j of the bit-reversed LDE, its
+  // next row sits at next_position(j).  Window (natural = 1; proofs whose LDEs do not fit the device, prover.hip "stream"): tl / al
+  // / part / pt hold `count` + 1 consecutive rows k0 .. k0 + count of coset `hsel` in NATURAL order with column stride `stride`
+  // (the extra row serves the transition constraints of the last one), point j is row k0 + j and its next row is j + 1.
+  size_t stride, count, k0;
+  u32 natural, hsel;
 };
+__device__ __forceinline__ size_t q_next(const QArgs& A, size_t j) { return A.natural ? j + 1 : next_position(j, A.log_n); }
 
 #define TL(c) tl[(size_t)(c)*M2 + j]
 #define TN(c) tl[(size_t)(c)*M2 + jn]
@@ -131,7 +138,7 @@ __device__ __forceinline__ void mz_block(const u64* __restrict__ tl, size_t M2, 
 // writes its alpha-weighted partial sums, k_quotient_finish adds them.  Since acc_j = sum_e c_e alpha_j^(K-1-e) is
 // linear in the constraints, the split changes nothing but register pressure and the number of waves in flight.
 __device__ __forceinline__ void store_part(const QArgs& A, int part, size_t j, u64 tot0, u64 tot1) {
-  const size_t M2 = (size_t)2 << A.log_n;
+  const size_t M2 = A.stride;
   A.part[((size_t)part * 2 + 0) * M2 + j] = tot0;
   A.part[((size_t)part * 2 + 1) * M2 + j] = tot1;
 }
@@ -140,7 +147,7 @@ __device__ __forceinline__ void store_part(const QArgs& A, int part, size_t j, u
 template <class L, bool FIRST_A_IS_ONE>
 __device__ __forceinline__ void schedule_part(const QArgs& A, size_t j, size_t jn, int e, int part) {
   u64 tot0 = 0, tot1 = 0;
-  const size_t M2 = (size_t)2 << A.log_n;
+  const size_t M2 = A.stride;
   const u64* __restrict__ tl = A.tl;
   const u64* __restrict__ W0 = A.W;
   const u64* __restrict__ W1 = A.W + A.K;
@@ -209,8 +216,8 @@ __device__ __forceinline__ void schedule_part(const QArgs& A, size_t j, size_t j
 // and the store in natural order of the coset.
 __device__ __forceinline__ void finish_point(const QArgs& A, const StarkShape& sh, size_t j) {
   const unsigned log_n = A.log_n;
-  const size_t N = (size_t)1 << log_n, M2 = 2 * N;
-  const size_t jn = next_position(j, log_n);
+  const size_t N = (size_t)1 << log_n, M2 = A.stride;
+  const size_t jn = q_next(A, j);
   u64 tot0 = 0, tot1 = 0;
   for (int p = 0; p < A.n_parts; p++) {
     tot0 = gl_add(tot0, A.part[((size_t)p * 2 + 0) * M2 + j]);
@@ -220,8 +227,8 @@ __device__ __forceinline__ void finish_point(const QArgs& A, const StarkShape& s
   const u64 z_last = gl_sub(x, A.w_inv);
   lookup_and_ctl_constraints(sh, A.tl, A.al, M2, j, jn, A.W, A.W + A.K, sh.n_constraints, A.betas, A.gammas, lfirst, llast,
                              z_last, tot0, tot1);
-  const size_t h = j >> log_n;
-  const u32 k = bitrev32((u32)(j & (N - 1)), log_n);
+  const size_t h = A.natural ? A.hsel : j >> log_n;
+  const size_t k = A.natural ? A.k0 + j : (size_t)bitrev32((u32)(j & (N - 1)), log_n);
   A.out[(0 * 2 + h) * N + k] = gl_mul(tot0, A.zh_inv[h]);
   A.out[(1 * 2 + h) * N + k] = gl_mul(tot1, A.zh_inv[h]);
 }
