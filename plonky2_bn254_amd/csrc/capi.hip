@@ -54,6 +54,8 @@ int bn254s_ctx_create(int device_id, bn254s_ctx** out) {
   if (hipSetDevice(device_id) != hipSuccess) return BN254S_E_HIP;
   bn254s_ctx* c = new bn254s_ctx();
   c->device = device_id;
+  merkle_set_throughput_mode(getenv("BN254S_COOP_MAX_NODES") ? atol(getenv("BN254S_COOP_MAX_NODES")) : -1,
+                             getenv("BN254S_MERKLE_LEVEL_ASM") ? atoi(getenv("BN254S_MERKLE_LEVEL_ASM")) : -1);
   if (const char* e = getenv("BN254S_BIG_CAP")) c->big_cap = std::max(1, atoi(e));
   if (const char* e = getenv("BN254S_SCHED_FIFO")) c->big_fifo = atoi(e) != 0;
   c->big_cost[BIG_NTT] = c->big_cap;

@@ -10,6 +10,7 @@
 #include <deque>
 #include <functional>
 #include <thread>
+#include <atomic>
 #include <hip/hip_runtime.h>
 #include "../../include/bn254_stark.h"
 #include "gl_dev.h"
@@ -73,6 +74,7 @@ struct WorkPool {
   size_t limit = 0, n_busy = 0;  // proofs in flight <= limit (BN254S_SLOTS of the latest batch call)
   size_t n_waiting = 0, completions = 0;
   std::mutex retry_mu;  // one task at a time gives idle workspaces back and allocates again after BN254S_E_OOM
+  std::atomic<int> in_flight{0};  // = n_busy, readable without the mutex (the provers pick throughput / latency kernels by it)
   void start(size_t n, int device) {
     std::lock_guard<std::mutex> lk(mu);
     limit = n;
@@ -97,12 +99,14 @@ struct WorkPool {
             s = free_slot();
             busy[s] = 1;
             n_busy++;
+            in_flight.store((int)n_busy, std::memory_order_relaxed);
           }
           f(s);
           {
             std::lock_guard<std::mutex> lk3(mu);
             busy[s] = 0;
             n_busy--;
+            in_flight.store((int)n_busy, std::memory_order_relaxed);
             completions++;
           }
           cv.notify_one();  // a worker may be waiting for a free slot below the limit

@@ -69,6 +69,11 @@ __global__ __launch_bounds__(256) void k_leaf_copy(const u64* __restrict__ data,
   o[1] = make_ulonglong2(s[2], s[3]);
 }
 
+// ASM = false: the compiler's permutation (one wave per SIMD here, 2^16 / 2^15 nodes: it keeps twelve independent S-boxes in flight
+// and finishes a lone wave in 60 us; the hand-scheduled one is built for issue-bound launches and takes 90 us alone).
+// ASM = true: the hand-scheduled permutation, half the instructions: for proofs that run beside many others, where the issue slots
+// count and the latency of one level does not (merkle_set_throughput_mode).
+template <bool ASM>
 __global__ __launch_bounds__(256) void k_merkle_level(const u64* __restrict__ in, u64* __restrict__ out, size_t n_out) {
   LATENCY_KERNEL_PRIO();
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -77,9 +82,8 @@ __global__ __launch_bounds__(256) void k_merkle_level(const u64* __restrict__ in
   ulonglong2 a = p[0], b = p[1], c = p[2], d = p[3];
   u64 s[12] = {a.x, a.y, b.x, b.y, c.x, c.y, d.x, d.y, 0, 0, 0, 0};
 #if defined(__HIP_DEVICE_COMPILE__)
-  // one wave per SIMD here (2^16 / 2^15 nodes): the compiler's permutation keeps twelve independent S-boxes in flight and
-  // finishes a lone wave in 60 us; the hand-scheduled one is built for issue-bound launches and takes 90 us alone
-  poseidon_permute_plain(s);
+  if constexpr (ASM) poseidon_permute(s);
+  else poseidon_permute_plain(s);
 #endif
   ulonglong2* o = reinterpret_cast<ulonglong2*>(out + 4 * i);
   o[0] = make_ulonglong2(s[0], s[1]);
@@ -87,7 +91,21 @@ __global__ __launch_bounds__(256) void k_merkle_level(const u64* __restrict__ in
 }
 
 // ---- small trees: one permutation per 16 lanes (poseidon_permute_coop) ----------------------------------------------------
-static constexpr size_t COOP_MAX_NODES = 16384;  // above this a level fills the GPU with one-lane permutations anyway
+// Levels of at most this many nodes use the cooperative (16 lanes per permutation) kernels: a fifth of the latency at five times the
+// instructions.  Two modes, chosen per call by the prover (same digests either way):
+//   latency (a proof alone or with few others): cooperative up to 16384 nodes, the compiler's permutation for the two one-lane levels;
+//   throughput (many proofs in flight: issue slots count, the latency of one level does not): cooperative up to 512 nodes, the
+//   hand-scheduled permutation for all one-lane levels.  bench.py, 32 proofs in flight (tools/gpu_merkle_mode.sh): 87.7-88.8 ->
+//   90.0-90.6 proofs/s with thresholds 1024 / 256 (0: 89.2; the level kernel alone: no change).
+// BN254S_COOP_MAX_NODES / BN254S_MERKLE_LEVEL_ASM override both modes (tuning).
+static long COOP_OVERRIDE = -1;
+static int LEVEL_ASM_OVERRIDE = -1;
+void merkle_set_throughput_mode(long coop_max_nodes, int level_asm) {
+  COOP_OVERRIDE = coop_max_nodes;
+  LEVEL_ASM_OVERRIDE = level_asm;
+}
+static size_t coop_max_nodes(int mode) { return COOP_OVERRIDE >= 0 ? (size_t)COOP_OVERRIDE : mode == MERKLE_THROUGHPUT ? 512 : 16384; }
+static bool level_asm(int mode) { return LEVEL_ASM_OVERRIDE >= 0 ? LEVEL_ASM_OVERRIDE != 0 : mode == MERKLE_THROUGHPUT; }
 
 __global__ __launch_bounds__(256) void k_merkle_level_coop(const u64* __restrict__ in, u64* __restrict__ out, size_t n_out) {
   LATENCY_KERNEL_PRIO();
@@ -117,7 +135,8 @@ __global__ __launch_bounds__(256) void k_leaf_hash_coop(const u64* __restrict__ 
 }
 
 void merkle_leaves(const u64* data, size_t leaf_stride, size_t elem_stride, int leaf_len, int log_leaves, u64* tree,
-                   hipStream_t s) {
+                   hipStream_t s, int mode) {
+  const size_t COOP_MAX_NODES = coop_max_nodes(mode);
   size_t n = (size_t)1 << log_leaves;
   if (leaf_len <= 4) {
     k_leaf_copy<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(data, leaf_stride, elem_stride, leaf_len, n, tree);
@@ -170,24 +189,27 @@ void merkle_absorb(const u64* data, size_t elem_stride, int ncols, int log_leave
   k_leaf_absorb<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(data, elem_stride, ncols, n, state, first ? 1 : 0, digests);
 }
 
-void merkle_upper(int log_leaves, int cap_height, u64* tree, hipStream_t s) {
+void merkle_upper(int log_leaves, int cap_height, u64* tree, hipStream_t s, int mode) {
+  const size_t COOP_MAX_NODES = coop_max_nodes(mode);
+  const bool MERKLE_LEVEL_ASM = level_asm(mode);
   for (int l = 0; l < log_leaves - cap_height; l++) {
     size_t n_out = (size_t)1 << (log_leaves - l - 1);
     const u64* in = tree + 4 * merkle_level_offset(log_leaves, l);
     u64* out = tree + 4 * merkle_level_offset(log_leaves, l + 1);
     if (n_out <= COOP_MAX_NODES) k_merkle_level_coop<<<(unsigned)((16 * n_out + 255) / 256), 256, 0, s>>>(in, out, n_out);
-    else k_merkle_level<<<(unsigned)((n_out + 255) / 256), 256, 0, s>>>(in, out, n_out);
+    else if (MERKLE_LEVEL_ASM) k_merkle_level<true><<<(unsigned)((n_out + 255) / 256), 256, 0, s>>>(in, out, n_out);
+    else k_merkle_level<false><<<(unsigned)((n_out + 255) / 256), 256, 0, s>>>(in, out, n_out);
   }
 }
 
 void merkle_build(const u64* data, size_t leaf_stride, size_t elem_stride, int leaf_len, int log_leaves, int cap_height,
-                  u64* tree, hipStream_t s) {
-  merkle_leaves(data, leaf_stride, elem_stride, leaf_len, log_leaves, tree, s);
-  merkle_upper(log_leaves, cap_height, tree, s);
+                  u64* tree, hipStream_t s, int mode) {
+  merkle_leaves(data, leaf_stride, elem_stride, leaf_len, log_leaves, tree, s, mode);
+  merkle_upper(log_leaves, cap_height, tree, s, mode);
 }
 
 // loads this translation unit's code object (the HIP runtime defers that to the first launch otherwise)
 void merkle_module_warm() {
   hipFuncAttributes a;
-  (void)hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_merkle_level));
+  (void)hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_merkle_level<false>));
 }

@@ -303,6 +303,8 @@ static int prove_on_slot(bn254s_ctx* c, Slot& sl, int kind, const bn254s_params&
       merkle_absorb(d_ldechunk_fwd, M2, cn, (int)log_m2_fwd, d_sponge_fwd, c0 == 0, c0 + cn == nc ? tree : nullptr, st);
     }
   };
+  // proofs running beside this one right now: the small Merkle levels use their throughput kernels then (merkle.h; same digests)
+  auto mmode = [&]() { return c->workers.in_flight.load(std::memory_order_relaxed) >= 4 ? MERKLE_THROUGHPUT : MERKLE_LATENCY; };
   const std::vector<int> arities = fri_arities(P, log_n);
   const int L = (int)arities.size();
   if (L > FRI_MAX_LAYERS) return BN254S_E_UNSUPPORTED;
@@ -476,7 +478,7 @@ static int prove_on_slot(bn254s_ctx* c, Slot& sl, int kind, const bn254s_params&
       merkle_leaves(d_tlde, 1, M2, W, log_m2, d_ttree, st);
     }
   }
-  merkle_upper(log_m2, P.cap_height, d_ttree, st);
+  merkle_upper(log_m2, P.cap_height, d_ttree, st, mmode());
   u64 caps[3][64];
   CHK(hipMemcpyAsync(caps[0], d_ttree + cap_off, CAPW * 8, hipMemcpyDeviceToHost, st));
   se(ST_TRACE_MERKLE);
@@ -540,7 +542,7 @@ static int prove_on_slot(bn254s_ctx* c, Slot& sl, int kind, const bn254s_params&
       merkle_leaves(d_alde, 1, M2, A, log_m2, d_atree, st);
     }
   }
-  merkle_upper(log_m2, P.cap_height, d_atree, st);
+  merkle_upper(log_m2, P.cap_height, d_atree, st, mmode());
   CHK(hipMemcpyAsync(caps[1], d_atree + cap_off, CAPW * 8, hipMemcpyDeviceToHost, st));
   se(ST_AUX_MERKLE);
   CHK(hipStreamSynchronize(st));
@@ -610,7 +612,7 @@ static int prove_on_slot(bn254s_ctx* c, Slot& sl, int kind, const bn254s_params&
   se(ST_QUOTIENT);
   sb(ST_QUOTIENT_COMMIT);
   do_lde(d_qcoef, d_qlde, NQ);
-  merkle_build(d_qlde, 1, M2, NQ, log_m2, P.cap_height, d_qtree, st);
+  merkle_build(d_qlde, 1, M2, NQ, log_m2, P.cap_height, d_qtree, st, mmode());
   CHK(hipMemcpyAsync(caps[2], d_qtree + cap_off, CAPW * 8, hipMemcpyDeviceToHost, st));
   se(ST_QUOTIENT_COMMIT);
   CHK(hipStreamSynchronize(st));
@@ -727,7 +729,7 @@ static int prove_on_slot(bn254s_ctx* c, Slot& sl, int kind, const bn254s_params&
   const u64 inv16 = gl_inv(16);
   for (int l = 0; l < L; l++) {
     const int lg = (int)lm - 4;
-    merkle_build(vals, 32, 1, 32, lg, P.cap_height, ftree, st);
+    merkle_build(vals, 32, 1, 32, lg, P.cap_height, ftree, st, mmode());
     CHK(hipMemcpyAsync(layer_caps[l].data(), ftree + 4 * merkle_level_offset(lg, lg - P.cap_height), CAPW * 8,
                        hipMemcpyDeviceToHost, st));
     CHK(hipStreamSynchronize(st));
