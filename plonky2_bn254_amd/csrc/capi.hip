@@ -58,6 +58,7 @@ int bn254s_ctx_create(int device_id, bn254s_ctx** out) {
                              getenv("BN254S_MERKLE_LEVEL_ASM") ? atoi(getenv("BN254S_MERKLE_LEVEL_ASM")) : -1);
   if (const char* e = getenv("BN254S_BIG_CAP")) c->big_cap = std::max(1, atoi(e));
   if (const char* e = getenv("BN254S_SCHED_FIFO")) c->big_fifo = atoi(e) != 0;
+  if (const char* e = getenv("BN254S_NTT_CONVOY")) c->big_convoy = std::max(0, atoi(e));
   c->big_cost[BIG_NTT] = c->big_cap;
   const char* cost_env[3] = {"BN254S_BIG_COST_NTT", "BN254S_BIG_COST_EXCL", "BN254S_BIG_COST_HASH"};
   for (int k = 0; k < 3; k++) {
