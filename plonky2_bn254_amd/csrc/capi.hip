@@ -59,12 +59,14 @@ int bn254s_ctx_create(int device_id, bn254s_ctx** out) {
   if (const char* e = getenv("BN254S_BIG_CAP")) c->big_cap = std::max(1, atoi(e));
   if (const char* e = getenv("BN254S_SCHED_FIFO")) c->big_fifo = atoi(e) != 0;
   if (const char* e = getenv("BN254S_NTT_CONVOY")) c->big_convoy = std::max(0, atoi(e));
+  if (const char* e = getenv("BN254S_HASH_SPLIT")) c->hash_split = std::min(8, std::max(1, atoi(e)));
   c->big_cost[BIG_NTT] = c->big_cap;
   const char* cost_env[3] = {"BN254S_BIG_COST_NTT", "BN254S_BIG_COST_EXCL", "BN254S_BIG_COST_HASH"};
   for (int k = 0; k < 3; k++) {
     if (const char* e = getenv(cost_env[k])) c->big_cost[k] = atoi(e);
     c->big_cost[k] = std::min(c->big_cap, std::max(0, c->big_cost[k]));
   }
+  c->big_cost[BIG_HASH_PART] = std::max(1, c->big_cost[BIG_HASH] / c->hash_split);
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
     delete c;
     return BN254S_E_HIP;

@@ -59,7 +59,7 @@ struct Slot {
   std::vector<hipEvent_t> events;  // stage begin / end pairs, created on first use and kept for the slot's lifetime
 };
 
-enum { BIG_NTT = 0, BIG_EXCL = 1, BIG_HASH = 2 };
+enum { BIG_NTT = 0, BIG_EXCL = 1, BIG_HASH = 2, BIG_HASH_PART = 3 };
 
 // The host threads that drive the slots: a worker takes the next proof queued by the batch entry points (arrival order, across
 // calls) and the lowest free slot - the first proofs of the next batch start while the last proofs of the current one finish
@@ -195,7 +195,8 @@ struct bn254s_ctx : BufPool {
   // 15 / 3 / 3: 88.2; 18: 85.6; an NTT stage that shares the GPU (cost 6 of 9) gains 3 % and doubles its own time.
   // BN254S_BIG_CAP / BN254S_BIG_COST_NTT / BN254S_BIG_COST_EXCL / BN254S_BIG_COST_HASH / BN254S_SCHED_FIFO override (tuning only; FIFO
   // admission is the default, BN254S_SCHED_FIFO=0 switches it off).
-  int big_cap = 12, big_cost[3] = {12, 2, 4}, big_used = 0;  // indexed by BIG_NTT, BIG_EXCL, BIG_HASH
+  int big_cap = 12, big_cost[4] = {12, 2, 4, 2}, big_used = 0;  // indexed by BIG_NTT, BIG_EXCL, BIG_HASH, BIG_HASH_PART
+  int hash_split = 1;  // BN254S_HASH_SPLIT: a 2^16-row proof's leaf hash as this many sections of cost big_cost[BIG_HASH] / split
   bool big_fifo = true;  // BN254S_SCHED_FIFO=0: the unordered semaphore (A/B runs)
   // Waiters in arrival order.  The head is admitted as soon as it fits.  One exception ("convoy"): an NTT stage needs the whole
   // capacity, i.e. the GPU drains before it starts; when it ends and other NTT stages are waiting further back, up to

@@ -22,6 +22,9 @@ void merkle_build(const u64* data, size_t leaf_stride, size_t elem_stride, int l
 void merkle_leaves(const u64* data, size_t leaf_stride, size_t elem_stride, int leaf_len, int log_leaves, u64* tree,
                    hipStream_t s, int mode = MERKLE_LATENCY);
 void merkle_upper(int log_leaves, int cap_height, u64* tree, hipStream_t s, int mode = MERKLE_LATENCY);
+// the leaf hash of leaves [j0, j0 + cnt) of a wide commitment (leaf_len > 4, cnt a multiple of 256)
+void merkle_leaves_range(const u64* data, size_t leaf_stride, size_t elem_stride, int leaf_len, size_t j0, size_t cnt, u64* tree,
+                         hipStream_t s);
 // Streaming leaf hash: absorbs `ncols` more columns (data[c * elem_stride + j]) into the resident sponge states [12][2^log_leaves];
 // `first` starts from the zero state, digests != nullptr (last chunk of the commitment) writes the leaf digests (tree level 0).
 void merkle_absorb(const u64* data, size_t elem_stride, int ncols, int log_leaves, u64* state, bool first, u64* digests, hipStream_t s);

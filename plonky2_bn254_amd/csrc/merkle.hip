@@ -184,6 +184,16 @@ __global__ __launch_bounds__(256) void k_leaf_absorb(const u64* __restrict__ dat
     for (int l = 0; l < 12; l++) state[(size_t)l * n_leaves + j] = s[l];
   }
 }
+// leaves [j0, j0 + cnt) only (cnt a multiple of 256; leaf_len > 4): a commitment's leaf hash cut into several launches
+void merkle_leaves_range(const u64* data, size_t leaf_stride, size_t elem_stride, int leaf_len, size_t j0, size_t cnt, u64* tree,
+                         hipStream_t s) {
+  size_t per_launch = std::min(cnt, (size_t)1 << 27);
+  if (leaf_stride && per_launch * leaf_stride > ((size_t)1 << 29)) per_launch = std::max((size_t)256, ((((size_t)1 << 29) / leaf_stride) / 256) * 256);
+  for (size_t a = 0; a < cnt; a += per_launch) {
+    const size_t n = std::min(per_launch, cnt - a);
+    k_leaf_hash<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(data + (j0 + a) * leaf_stride, leaf_stride, elem_stride, leaf_len, n, tree + 4 * (j0 + a));
+  }
+}
 void merkle_absorb(const u64* data, size_t elem_stride, int ncols, int log_leaves, u64* state, bool first, u64* digests, hipStream_t s) {
   const size_t n = (size_t)1 << log_leaves;
   k_leaf_absorb<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(data, elem_stride, ncols, n, state, first ? 1 : 0, digests);

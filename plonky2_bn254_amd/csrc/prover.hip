@@ -303,6 +303,20 @@ static int prove_on_slot(bn254s_ctx* c, Slot& sl, int kind, const bn254s_params&
       merkle_absorb(d_ldechunk_fwd, M2, cn, (int)log_m2_fwd, d_sponge_fwd, c0 == 0, c0 + cn == nc ? tree : nullptr, st);
     }
   };
+  // leaf hash of a resident commitment: one GPU-filling section, or (BN254S_HASH_SPLIT, 2^16-row proofs) several shorter ones
+  auto hash_sections = [&](const u64* lde, int width, u64* tree) {
+    const int S = log_n == 16 ? c->hash_split : 1;
+    if (S <= 1) {
+      BigSection big(c, st, BIG_HASH);
+      merkle_leaves(lde, 1, M2, width, log_m2_fwd, tree, st);
+      return;
+    }
+    const size_t cnt = M2 / S;
+    for (int k = 0; k < S; k++) {
+      BigSection big(c, st, BIG_HASH_PART);
+      merkle_leaves_range(lde, 1, M2, width, (size_t)k * cnt, cnt, tree, st);
+    }
+  };
   // proofs running beside this one right now: the small Merkle levels use their throughput kernels then (merkle.h; same digests)
   auto mmode = [&]() { return c->workers.in_flight.load(std::memory_order_relaxed) >= 4 ? MERKLE_THROUGHPUT : MERKLE_LATENCY; };
   const std::vector<int> arities = fri_arities(P, log_n);
@@ -472,11 +486,8 @@ static int prove_on_slot(bn254s_ctx* c, Slot& sl, int kind, const bn254s_params&
       do_commit_ntt(d_tvals, d_tcoef, d_tlde, W);
       se(ST_TRACE_NTT);
     }
-    {
-      BigSection big(c, st, BIG_HASH);
-      sb(ST_TRACE_MERKLE);
-      merkle_leaves(d_tlde, 1, M2, W, log_m2, d_ttree, st);
-    }
+    sb(ST_TRACE_MERKLE);
+    hash_sections(d_tlde, W, d_ttree);
   }
   merkle_upper(log_m2, P.cap_height, d_ttree, st, mmode());
   u64 caps[3][64];
@@ -536,11 +547,8 @@ static int prove_on_slot(bn254s_ctx* c, Slot& sl, int kind, const bn254s_params&
       do_commit_ntt(d_avals, d_acoef, d_alde, A);
       se(ST_AUX_NTT);
     }
-    {
-      BigSection big(c, st, BIG_HASH);
-      sb(ST_AUX_MERKLE);
-      merkle_leaves(d_alde, 1, M2, A, log_m2, d_atree, st);
-    }
+    sb(ST_AUX_MERKLE);
+    hash_sections(d_alde, A, d_atree);
   }
   merkle_upper(log_m2, P.cap_height, d_atree, st, mmode());
   CHK(hipMemcpyAsync(caps[1], d_atree + cap_off, CAPW * 8, hipMemcpyDeviceToHost, st));
