@@ -21,7 +21,8 @@ def resources(path):
             continue
         k, v = m.group(1), m.group(2)
         if k == "Function Name":
-            cur = {"name": subprocess.run(["c++filt", v], capture_output=True, text=True).stdout.strip().split("(")[0]}
+            full = subprocess.run(["c++filt", v], capture_output=True, text=True).stdout.strip().replace("(anonymous namespace)::", "")
+            cur = {"name": full.split("(")[0]}
             rows.append(cur)
         elif cur is not None:
             cur[k.split(" ")[0]] = v
