@@ -187,9 +187,11 @@ def init_dist(args):
     if world != args.gpus and rank == 0:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
     dist = None
-    if world > 1:
+    # BENCH_FORCE_DIST=1: a process group even for one rank (tests: the RCCL branch of the cap gather on a one-GPU box)
+    if world > 1 or os.environ.get("BENCH_FORCE_DIST"):
         import torch.distributed as dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29733")
         # BENCH_BACKEND=gloo / BENCH_DEVICE=0 exist only to rehearse the N>1 path on a one-GPU box
         dist_mod.init_process_group(backend=os.environ.get("BENCH_BACKEND", "nccl"), rank=rank, world_size=world)
         dist = dist_mod

@@ -158,3 +158,19 @@ def test_bench_two_ranks_map_to_g2_child_process(gpu_ctx):
     assert out["n_gpus"] == 2 and out["unit"] == "inputs/s" and out["value"] > 0 and out["scaling"] == "strong"
     assert "configs[4]" in out["config"]["workload"] and "4096 Fq2 inputs = 64 Fq-exp proofs + 32 G2 proofs" in out["config"]["workload"]
     assert out["checked"]["verified_proofs_rank0_last_step"] == 32 + 16
+
+
+def test_bench_cap_gather_over_rccl_one_rank(gpu_ctx):
+    """The nccl (= RCCL) branch of bench.py's cap gather: device tensors, int64 view of the u64 caps, all_gather, barrier and the
+    MAX / MIN all-reduces - with a process group of ONE rank (two ranks cannot share a GPU under RCCL), so that the first multi-GPU
+    run of the driver does not meet this code for the first time."""
+    gpu_ctx.trim()
+    env = dict(os.environ, BENCH_FORCE_DIST="1", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT="29717", HSA_ENABLE_IPC_MODE_LEGACY="0", BN254S_SLOTS="16")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--steps-in-flight", "2",
+           "--no-extras", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["n_gpus"] == 1 and out["checked"] == {"verified_proofs": 8, "caps_match": True, "batch_equals_single": True}
+    assert out["value"] > 0
