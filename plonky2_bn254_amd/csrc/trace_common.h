@@ -59,15 +59,15 @@ static constexpr int MZ_LANES = 64;
 typedef __attribute__((address_space(3))) long long mz_lds_t;
 static __device__ __noinline__ void gen_modulus_zero_lds(const mz_lds_t* in_lds, u64* __restrict__ trace, size_t N, size_t row, int col0,
                                                          int* err) {
-  long long in[31];
-#pragma unroll
-  for (int i = 0; i < 31; i++) in[i] = in_lds[i * MZ_LANES];
+  // Everything is streamed from the LDS slots (in(i)) instead of being held in arrays: the function is called from kernels that keep
+  // a dozen coordinates alive across the call, and its own registers add to theirs.
+  auto in = [&](int i) -> long long { return in_lds[i * MZ_LANES]; };
   // low 288 bits of V = sum in[i] 2^(16 i), two's complement
   u32 v[9];
   long long carry = 0;
 #pragma unroll
   for (int w = 0; w < 9; w++) {
-    long long t = carry + in[2 * w] + (in[2 * w + 1] << 16);
+    long long t = carry + in(2 * w) + (in(2 * w + 1) << 16);
     v[w] = (u32)t;
     carry = t >> 32;
   }
@@ -94,39 +94,40 @@ static __device__ __noinline__ void gen_modulus_zero_lds(const mz_lds_t* in_lds,
   }
 #pragma unroll
   for (int k = 0; k < 9; k++) nonzero |= q[k] != 0;
-  int qabs[17];
-#pragma unroll
-  for (int i = 0; i < 17; i++) qabs[i] = (int)((q[i >> 1] >> (16 * (i & 1))) & 0xFFFF);
   if ((q[8] >> 16) != 0) atomicCAS(err, 0, BN254S_E_INTERNAL);  // quotient wider than 17 limbs
-  // constr = in - quot(x) * m(x)
-  long long constr[32];
-#pragma unroll
-  for (int i = 0; i < 31; i++) constr[i] = in[i];
-  constr[31] = 0;
+  u64* out = trace + (size_t)col0 * N + row;
+  out[0] = (!neg && nonzero) ? 1 : 0;
+  int qs[17];  // signed limbs of the quotient
   const int sgn = neg ? -1 : 1;
 #pragma unroll
   for (int i = 0; i < 17; i++) {
-    long long qi = (long long)(sgn * qabs[i]);
-#pragma unroll
-    for (int j = 0; j < 16; j++) constr[i + j] -= qi * MOD_LIMBS[j];
+    const int qa = (int)((q[i >> 1] >> (16 * (i & 1))) & 0xFFFF);
+    out[(size_t)(1 + i) * N] = (u64)qa;
+    qs[i] = sgn * qa;
   }
-  u64* out = trace + (size_t)col0 * N + row;
-  out[0] = (!neg && nonzero) ? 1 : 0;
-#pragma unroll
-  for (int i = 0; i < 17; i++) out[(size_t)(1 + i) * N] = (u64)qabs[i];
+  // constr = in - quot(x) * m(x), coefficient d formed when the division below needs it;
   // aux = constr / (x - 2^16) (pol_remove_root_2exp), shifted by 2^29, split in 16-bit halves
-  long long a = -(constr[0] >> 16);
+  long long a = 0;
   bool bad = false;
 #pragma unroll
-  for (int d = 0; d < 31; d++) {
-    if (d > 0) a = (a - constr[d]) >> 16;
-    long long sh = a + (1LL << 29);
+  for (int d = 0; d < 32; d++) {
+    long long cd = d < 31 ? in(d) : 0;
+#pragma unroll
+    for (int i = 0; i < 17; i++) {
+      const int jdx = d - i;
+      if (jdx >= 0 && jdx < 16) cd -= (long long)qs[i] * MOD_LIMBS[jdx];
+    }
+    if (d == 31) {  // exactness: the last carry must vanish, otherwise `in` was not a multiple of p
+      bad |= a != cd;
+      break;
+    }
+    a = d == 0 ? -(cd >> 16) : (a - cd) >> 16;
+    const long long sh = a + (1LL << 29);
     bad |= (sh < 0) | (sh > (1LL << 30));
     out[(size_t)(18 + d) * N] = (u64)(sh & 0xFFFF);
     out[(size_t)(49 + d) * N] = (u64)((sh >> 16) & 0xFFFF);
   }
-  // exactness: the last carry must vanish, otherwise `in` was not a multiple of p
-  if (bad || a != constr[31]) atomicCAS(err, 0, BN254S_E_INTERNAL);
+  if (bad) atomicCAS(err, 0, BN254S_E_INTERNAL);
 }
 
 // stores the coefficients to the calling lane's LDS slots and calls the function above; `slots` = &buffer[0][lane] of a

@@ -260,6 +260,82 @@ __device__ __forceinline__ void ext_mul_c1(const int* x0, const int* x1, const i
   for (int i = 0; i < 31; i++) out[i] += t[i];
 }
 
+// ---- k_g2_rows helpers: packed limbs, limb products accumulated in LDS --------------------------------------------------------
+// The sixteen 16-bit limbs of a coordinate are kept two to a register (P16).  The 31-coefficient polynomial of a witness block lives
+// in the lane's LDS slots (the argument buffer of gen_modulus_zero_lds, trace_common.h); a limb product is a called function that
+// unpacks its operands, forms the 31 coefficients in its own registers and adds them to the slots.  The row kernel itself then
+// holds little more than the fourteen packed coordinates.  (Round 2 held fourteen unpacked arrays and two or three polynomials:
+// 256 + 256 registers and 784 B of scratch per lane.)
+struct P16 {
+  u32 w[8];
+};
+__device__ __forceinline__ P16 p16_pack(const fq& m) {
+  const fqw cw = fq_to_canonical(m);
+  P16 p;
+#pragma unroll
+  for (int i = 0; i < 8; i++) p.w[i] = (u32)(cw.l[i >> 1] >> (32 * (i & 1)));
+  return p;
+}
+__device__ __forceinline__ void p16_unpack(const P16& p, int* l) {
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    l[2 * i] = (int)(p.w[i] & 0xFFFF);
+    l[2 * i + 1] = (int)(p.w[i] >> 16);
+  }
+}
+// slots += coef * (x - [mode 1] sub) * (y - [mode 2] sub) as limb polynomials; cm = coef * 4 + mode.  The packed operands travel as
+// vector-typed arguments (registers; a struct argument of this size goes through the stack, i.e. scratch memory).
+typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+static __device__ __noinline__ void mac_lds_v(mz_lds_t* slots, int cm, u32x4 xa, u32x4 xb, u32x4 ya, u32x4 yb, u32x4 sa, u32x4 sb) {
+  const int mode = cm & 3, coef = cm >> 2;
+  int a[16], b[16], t[16];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    a[2 * i] = (int)(xa[i] & 0xFFFF);
+    a[2 * i + 1] = (int)(xa[i] >> 16);
+    a[8 + 2 * i] = (int)(xb[i] & 0xFFFF);
+    a[8 + 2 * i + 1] = (int)(xb[i] >> 16);
+    b[2 * i] = (int)(ya[i] & 0xFFFF);
+    b[2 * i + 1] = (int)(ya[i] >> 16);
+    b[8 + 2 * i] = (int)(yb[i] & 0xFFFF);
+    b[8 + 2 * i + 1] = (int)(yb[i] >> 16);
+    t[2 * i] = (int)(sa[i] & 0xFFFF);
+    t[2 * i + 1] = (int)(sa[i] >> 16);
+    t[8 + 2 * i] = (int)(sb[i] & 0xFFFF);
+    t[8 + 2 * i + 1] = (int)(sb[i] >> 16);
+  }
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    a[i] -= mode == 1 ? t[i] : 0;
+    b[i] -= mode == 2 ? t[i] : 0;
+    a[i] *= coef;
+  }
+  long long out[31];
+#pragma unroll
+  for (int i = 0; i < 31; i++) out[i] = 0;
+#pragma unroll
+  for (int i = 0; i < 16; i++)
+#pragma unroll
+    for (int j = 0; j < 16; j++) out[i + j] += (long long)a[i] * b[j];
+#pragma unroll
+  for (int i = 0; i < 31; i++) slots[i * MZ_LANES] += out[i];
+}
+__device__ __forceinline__ void mac_lds(mz_lds_t* slots, int cm, const P16& x, const P16& y, const P16& sub) {
+  mac_lds_v(slots, cm, u32x4{x.w[0], x.w[1], x.w[2], x.w[3]}, u32x4{x.w[4], x.w[5], x.w[6], x.w[7]}, u32x4{y.w[0], y.w[1], y.w[2], y.w[3]},
+            u32x4{y.w[4], y.w[5], y.w[6], y.w[7]}, u32x4{sub.w[0], sub.w[1], sub.w[2], sub.w[3]},
+            u32x4{sub.w[4], sub.w[5], sub.w[6], sub.w[7]});
+}
+__device__ __forceinline__ void lin_lds(mz_lds_t* slots, int coef, const P16& x) {
+  int a[16];
+  p16_unpack(x, a);
+#pragma unroll
+  for (int i = 0; i < 16; i++) slots[i * MZ_LANES] += (long long)(coef * a[i]);
+}
+__device__ __forceinline__ void zero_lds(mz_lds_t* slots) {
+#pragma unroll
+  for (int i = 0; i < 31; i++) slots[i * MZ_LANES] = 0;
+}
+
 __global__ __launch_bounds__(64) void k_g2_rows(const u64* __restrict__ scalars, int n, Soa2 px, Soa2 py, Soa2 pz,
                                                 const u64* __restrict__ zni, const u64* __restrict__ inv_out,
                                                 const u64* __restrict__ rf_tbl, u64* __restrict__ trace, size_t N,
@@ -275,133 +351,147 @@ __global__ __launch_bounds__(64) void k_g2_rows(const u64* __restrict__ scalars,
   u64 s[4];
   for (int i = 0; i < 4; i++) s[i] = scalars[4 * inst + i];
   const bool bitk = (s[k >> 6] >> (k & 63)) & 1;
-  Aff2 a, b, c, sum, dbl;
-  if (adding) {
-    a = affine_pt2(px, py, pz, zni, cnt, (size_t)sum_point(s, k) * n + inst);
-    b = affine_pt2(px, py, pz, zni, cnt, (size_t)(257 + k) * n + inst);
-    c = affine_pt2(px, py, pz, zni, cnt, (size_t)(1 + k) * n + inst);
-    dbl = b;
-    sum = bitk ? c : a;
-  } else {
-    a = affine_pt2(px, py, pz, zni, cnt, (size_t)(257 + k) * n + inst);
-    b = a;
-    c = affine_pt2(px, py, pz, zni, cnt, (size_t)(258 + k) * n + inst);
-    dbl = c;
-    sum = affine_pt2(px, py, pz, zni, cnt, (size_t)sum_point(s, k + 1) * n + inst);
-  }
-  const fq2 dxm = fq2_sub(b.x, a.x);
-  const bool z0 = fq_is_zero(dxm.c0), z1 = fq_is_zero(dxm.c1), x_eq = z0 && z1;
-  const fq2 den = x_eq ? fq2_dbl(a.y) : dxm;
-  const fq2 di = fq2_inv_from_norm_inv(den, ld_fq(inv_out, 3 * nrows, r));
-  fq2 lambda;
-  if (!x_eq) {
-    lambda = fq2_mul(fq2_sub(b.y, a.y), di);  // g2/add.rs:73
-  } else {
-    fq2 xx = fq2_sqr(a.x);
-    lambda = fq2_mul(fq2_add(fq2_dbl(xx), xx), di);  // g2/add.rs:86
-  }
-  const fq inv0 = ld_fq(inv_out, 3 * nrows, nrows + r), inv1 = ld_fq(inv_out, 3 * nrows, 2 * nrows + r);
-
+  // Three affine points per row, one after the other (the field elements of a point are packed into limbs and dropped before the
+  // next conversion starts):  P1 = the running sum S (S_(k-1) on an adding row, S_k on a doubling row), P2 = D_k, P3 = C_k (adding)
+  // or D_(k+1) (doubling).   adding: a = P1, b = P2, c = P3, double = P2, sum = bit ? P3 : P1;   doubling: a = b = P2, c = P3,
+  // double = P3, sum = P1.
   auto put = [&](int col, u64 v) { trace[(size_t)col * N + r] = v; };
-  auto put16 = [&](int col, const int* l) {
+  auto put_p = [&](int col, const P16& p) {
 #pragma unroll
-    for (int i = 0; i < 16; i++) put(col + i, (u64)l[i]);
+    for (int i = 0; i < 8; i++) {
+      put(col + 2 * i, (u64)(p.w[i] & 0xFFFF));
+      put(col + 2 * i + 1, (u64)(p.w[i] >> 16));
+    }
   };
-  int ax0[16], ax1[16], ay0[16], ay1[16], bx0[16], bx1[16], cx0[16], cx1[16], l0[16], l1[16], t0[16], t1[16], u0[16], u1[16];
-  fq_to_limbs(a.x.c0, ax0); fq_to_limbs(a.x.c1, ax1); fq_to_limbs(a.y.c0, ay0); fq_to_limbs(a.y.c1, ay1);
-  fq_to_limbs(b.x.c0, bx0); fq_to_limbs(b.x.c1, bx1); fq_to_limbs(c.x.c0, cx0); fq_to_limbs(c.x.c1, cx1);
-  fq_to_limbs(lambda.c0, l0); fq_to_limbs(lambda.c1, l1);
-  put16(L::A, ax0); put16(L::A + 16, ax1); put16(L::A + 32, ay0); put16(L::A + 48, ay1);
-  put16(L::B, bx0); put16(L::B + 16, bx1);
-  put16(L::C, cx0); put16(L::C + 16, cx1);
-  put16(L::AUX + G2_AUX_LAMBDA, l0); put16(L::AUX + G2_AUX_LAMBDA + 16, l1);
-  fq_to_limbs(dbl.x.c0, t0); put16(L::DOUBLE, t0);
-  fq_to_limbs(dbl.x.c1, t0); put16(L::DOUBLE + 16, t0);
-  fq_to_limbs(dbl.y.c0, t0); put16(L::DOUBLE + 32, t0);
-  fq_to_limbs(dbl.y.c1, t0); put16(L::DOUBLE + 48, t0);
-  fq_to_limbs(sum.x.c0, t0); put16(L::SUM, t0);
-  fq_to_limbs(sum.x.c1, t0); put16(L::SUM + 16, t0);
-  fq_to_limbs(sum.y.c0, t0); put16(L::SUM + 32, t0);
-  fq_to_limbs(sum.y.c1, t0); put16(L::SUM + 48, t0);
+  auto sel = [&](bool first, const P16& x, const P16& y) {
+    P16 o;
+#pragma unroll
+    for (int i = 0; i < 8; i++) o.w[i] = first ? x.w[i] : y.w[i];
+    return o;
+  };
+  P16 ax0, ax1, ay0, ay1, bx0, bx1, by0, by1, l0, l1, s1x0, s1x1, s1y0, s1y1;
+  bool z0, z1, x_eq;
+  {
+    const Aff2 p1 = affine_pt2(px, py, pz, zni, cnt, (size_t)sum_point(s, adding ? k : k + 1) * n + inst);
+    const Aff2 p2 = affine_pt2(px, py, pz, zni, cnt, (size_t)(257 + k) * n + inst);
+    Aff2 a = p2;
+    if (adding) a = p1;
+    const Aff2& b = p2;
+    const fq2 dxm = fq2_sub(b.x, a.x);
+    z0 = fq_is_zero(dxm.c0);
+    z1 = fq_is_zero(dxm.c1);
+    x_eq = z0 && z1;
+    const fq2 den = x_eq ? fq2_dbl(a.y) : dxm;
+    const fq2 di = fq2_inv_from_norm_inv(den, ld_fq(inv_out, 3 * nrows, r));
+    fq2 lambda;
+    if (!x_eq) {
+      lambda = fq2_mul(fq2_sub(b.y, a.y), di);  // g2/add.rs:73
+    } else {
+      fq2 xx = fq2_sqr(a.x);
+      lambda = fq2_mul(fq2_add(fq2_dbl(xx), xx), di);  // g2/add.rs:86
+    }
+    ax0 = p16_pack(a.x.c0); ax1 = p16_pack(a.x.c1); ay0 = p16_pack(a.y.c0); ay1 = p16_pack(a.y.c1);
+    bx0 = p16_pack(b.x.c0); bx1 = p16_pack(b.x.c1); by0 = p16_pack(b.y.c0); by1 = p16_pack(b.y.c1);
+    l0 = p16_pack(lambda.c0); l1 = p16_pack(lambda.c1);
+    s1x0 = p16_pack(p1.x.c0); s1x1 = p16_pack(p1.x.c1); s1y0 = p16_pack(p1.y.c0); s1y1 = p16_pack(p1.y.c1);
+  }
+  put_p(L::A, ax0); put_p(L::A + 16, ax1); put_p(L::A + 32, ay0); put_p(L::A + 48, ay1);
+  put_p(L::B, bx0); put_p(L::B + 16, bx1); put_p(L::B + 32, by0); put_p(L::B + 48, by1);
+  put_p(L::AUX + G2_AUX_LAMBDA, l0); put_p(L::AUX + G2_AUX_LAMBDA + 16, l1);
+  P16 cx0, cx1, cy0, cy1;
+  {
+    const Aff2 p3 = affine_pt2(px, py, pz, zni, cnt, (size_t)(adding ? 1 + k : 258 + k) * n + inst);
+    cx0 = p16_pack(p3.x.c0); cx1 = p16_pack(p3.x.c1); cy0 = p16_pack(p3.y.c0); cy1 = p16_pack(p3.y.c1);
+  }
+  put_p(L::C, cx0); put_p(L::C + 16, cx1); put_p(L::C + 32, cy0); put_p(L::C + 48, cy1);
+  // double = adding ? b : c;  sum = adding ? (bit ? c : a (= P1)) : P1
+  put_p(L::DOUBLE, sel(adding, bx0, cx0)); put_p(L::DOUBLE + 16, sel(adding, bx1, cx1));
+  put_p(L::DOUBLE + 32, sel(adding, by0, cy0)); put_p(L::DOUBLE + 48, sel(adding, by1, cy1));
+  const bool sum_is_c = adding && bitk;
+  put_p(L::SUM, sel(sum_is_c, cx0, s1x0)); put_p(L::SUM + 16, sel(sum_is_c, cx1, s1x1));
+  put_p(L::SUM + 32, sel(sum_is_c, cy0, s1y0)); put_p(L::SUM + 48, sel(sum_is_c, cy1, s1y1));
   put(L::AUX + G2_AUX_IS_X_EQ, x_eq);
   put(L::AUX + G2_AUX_IS_C0_ZERO, z0);
   put(L::AUX + G2_AUX_IS_C1_ZERO, z1);
   put(L::AUX + G2_AUX_IS_X_EQ_FILTER, x_eq);
-
-  __shared__ long long mz_buf[31][MZ_LANES];  // the arguments of gen_modulus_zero (trace_common.h)
-  long long* const mz_slots = &mz_buf[0][threadIdx.x];
-  long long diff[31];
-  int dx0[16], dx1[16];
-#pragma unroll
-  for (int i = 0; i < 16; i++) {
-    dx0[i] = bx0[i] - ax0[i];
-    dx1[i] = bx1[i] - ax1[i];
+  const fq inv0 = ld_fq(inv_out, 3 * nrows, nrows + r), inv1 = ld_fq(inv_out, 3 * nrows, 2 * nrows + r);
+  __shared__ long long mz_buf[31][MZ_LANES];  // the polynomial of the current witness block (trace_common.h)
+  mz_lds_t* const slots = (mz_lds_t*)&mz_buf[0][threadIdx.x];
+  auto mac = [&](int coef, const P16& x, const P16* xs, const P16& y, const P16* ys) {
+    mac_lds(slots, coef * 4 + (xs ? 1 : ys ? 2 : 0), x, y, xs ? *xs : ys ? *ys : x);
+  };
+  auto emit = [&](int col) { gen_modulus_zero_lds(slots, trace, N, r, col, err); };
+  // is_modulus_zero witnesses of delta_x.c0 and delta_x.c1 (ext/is_modulus_zero.rs:35-36): (b.x - a.x).ck * inv_k - 1 + is_zero_k
+  {
+    const P16 t = p16_pack(inv0);
+    put_p(L::AUX + G2_AUX_C0_AUX, t);
+    zero_lds(slots);
+    mac(1, bx0, &ax0, t, nullptr);
+    slots[0] += (long long)z0 - 1;
+    emit(L::AUX + G2_AUX_C0_AUX + 16);
   }
-  // is_modulus_zero witnesses of delta_x.c0 and delta_x.c1 (ext/is_modulus_zero.rs:35-36)
-  fq_to_limbs(inv0, t0);
-  put16(L::AUX + G2_AUX_C0_AUX, t0);
-  pol_mul16(dx0, t0, diff);
-  diff[0] += (long long)z0 - 1;
-  gen_modulus_zero(diff, mz_slots, trace, N, r, L::AUX + G2_AUX_C0_AUX + 16, err);
-  fq_to_limbs(inv1, t0);
-  put16(L::AUX + G2_AUX_C1_AUX, t0);
-  pol_mul16(dx1, t0, diff);
-  diff[0] += (long long)z1 - 1;
-  gen_modulus_zero(diff, mz_slots, trace, N, r, L::AUX + G2_AUX_C1_AUX + 16, err);
+  {
+    const P16 t = p16_pack(inv1);
+    put_p(L::AUX + G2_AUX_C1_AUX, t);
+    zero_lds(slots);
+    mac(1, bx1, &ax1, t, nullptr);
+    slots[0] += (long long)z1 - 1;
+    emit(L::AUX + G2_AUX_C1_AUX + 16);
+  }
   // lambda witness
-  fq_to_limbs(b.y.c0, t0);  // b.y
-  fq_to_limbs(b.y.c1, t1);
-  put16(L::B + 32, t0);
-  put16(L::B + 48, t1);
-  if (!x_eq) {
-    ext_mul_c0(l0, l1, dx0, dx1, diff);
-#pragma unroll
-    for (int i = 0; i < 16; i++) diff[i] -= (long long)(t0[i] - ay0[i]);
-    gen_modulus_zero(diff, mz_slots, trace, N, r, L::AUX + G2_AUX_LAMBDA_AUX, err);
-    ext_mul_c1(l0, l1, dx0, dx1, diff);
-#pragma unroll
-    for (int i = 0; i < 16; i++) diff[i] -= (long long)(t1[i] - ay1[i]);
-    gen_modulus_zero(diff, mz_slots, trace, N, r, L::AUX + G2_AUX_LAMBDA_AUX + 80, err);
-  } else {
-    long long xx[31];
-    ext_mul_c0(l0, l1, ay0, ay1, diff);
-    ext_mul_c0(ax0, ax1, ax0, ax1, xx);
-#pragma unroll
-    for (int i = 0; i < 31; i++) diff[i] = 2 * diff[i] - 3 * xx[i];
-    gen_modulus_zero(diff, mz_slots, trace, N, r, L::AUX + G2_AUX_LAMBDA_AUX, err);
-    ext_mul_c1(l0, l1, ay0, ay1, diff);
-    ext_mul_c1(ax0, ax1, ax0, ax1, xx);
-#pragma unroll
-    for (int i = 0; i < 31; i++) diff[i] = 2 * diff[i] - 3 * xx[i];
-    gen_modulus_zero(diff, mz_slots, trace, N, r, L::AUX + G2_AUX_LAMBDA_AUX + 80, err);
+  if (!x_eq) {  // lambda * (b.x - a.x) - (b.y - a.y)
+    zero_lds(slots);
+    mac(1, l0, nullptr, bx0, &ax0);
+    mac(-1, l1, nullptr, bx1, &ax1);
+    lin_lds(slots, -1, by0);
+    lin_lds(slots, 1, ay0);
+    emit(L::AUX + G2_AUX_LAMBDA_AUX);
+    zero_lds(slots);
+    mac(1, l0, nullptr, bx1, &ax1);
+    mac(1, l1, nullptr, bx0, &ax0);
+    lin_lds(slots, -1, by1);
+    lin_lds(slots, 1, ay1);
+    emit(L::AUX + G2_AUX_LAMBDA_AUX + 80);
+  } else {  // 2 * lambda * a.y - 3 * a.x^2
+    zero_lds(slots);
+    mac(2, l0, nullptr, ay0, nullptr);
+    mac(-2, l1, nullptr, ay1, nullptr);
+    mac(-3, ax0, nullptr, ax0, nullptr);
+    mac(3, ax1, nullptr, ax1, nullptr);
+    emit(L::AUX + G2_AUX_LAMBDA_AUX);
+    zero_lds(slots);
+    mac(2, l0, nullptr, ay1, nullptr);
+    mac(2, l1, nullptr, ay0, nullptr);
+    mac(-6, ax0, nullptr, ax1, nullptr);
+    emit(L::AUX + G2_AUX_LAMBDA_AUX + 80);
   }
   // x witness: lambda^2 - (a.x + b.x + c.x)
-  ext_mul_c0(l0, l1, l0, l1, diff);
-#pragma unroll
-  for (int i = 0; i < 16; i++) diff[i] -= (long long)(ax0[i] + bx0[i] + cx0[i]);
-  gen_modulus_zero(diff, mz_slots, trace, N, r, L::AUX + G2_AUX_X_AUX, err);
-  ext_mul_c1(l0, l1, l0, l1, diff);
-#pragma unroll
-  for (int i = 0; i < 16; i++) diff[i] -= (long long)(ax1[i] + bx1[i] + cx1[i]);
-  gen_modulus_zero(diff, mz_slots, trace, N, r, L::AUX + G2_AUX_X_AUX + 80, err);
+  zero_lds(slots);
+  mac(1, l0, nullptr, l0, nullptr);
+  mac(-1, l1, nullptr, l1, nullptr);
+  lin_lds(slots, -1, ax0);
+  lin_lds(slots, -1, bx0);
+  lin_lds(slots, -1, cx0);
+  emit(L::AUX + G2_AUX_X_AUX);
+  zero_lds(slots);
+  mac(2, l0, nullptr, l1, nullptr);
+  lin_lds(slots, -1, ax1);
+  lin_lds(slots, -1, bx1);
+  lin_lds(slots, -1, cx1);
+  emit(L::AUX + G2_AUX_X_AUX + 80);
   // y witness: lambda*(c.x - a.x) + c.y + a.y
-  fq_to_limbs(c.y.c0, t0);
-  fq_to_limbs(c.y.c1, t1);
-  put16(L::C + 32, t0);
-  put16(L::C + 48, t1);
-#pragma unroll
-  for (int i = 0; i < 16; i++) {
-    u0[i] = cx0[i] - ax0[i];
-    u1[i] = cx1[i] - ax1[i];
-  }
-  ext_mul_c0(l0, l1, u0, u1, diff);
-#pragma unroll
-  for (int i = 0; i < 16; i++) diff[i] += (long long)(t0[i] + ay0[i]);
-  gen_modulus_zero(diff, mz_slots, trace, N, r, L::AUX + G2_AUX_Y_AUX, err);
-  ext_mul_c1(l0, l1, u0, u1, diff);
-#pragma unroll
-  for (int i = 0; i < 16; i++) diff[i] += (long long)(t1[i] + ay1[i]);
-  gen_modulus_zero(diff, mz_slots, trace, N, r, L::AUX + G2_AUX_Y_AUX + 80, err);
+  zero_lds(slots);
+  mac(1, l0, nullptr, cx0, &ax0);
+  mac(-1, l1, nullptr, cx1, &ax1);
+  lin_lds(slots, 1, cy0);
+  lin_lds(slots, 1, ay0);
+  emit(L::AUX + G2_AUX_Y_AUX);
+  zero_lds(slots);
+  mac(1, l0, nullptr, cx1, &ax1);
+  mac(1, l1, nullptr, cx0, &ax0);
+  lin_lds(slots, 1, cy1);
+  lin_lds(slots, 1, ay1);
+  emit(L::AUX + G2_AUX_Y_AUX + 80);
 
   for (int i = 0; i < 256; i++) {
     int src = (i + k) & 255;
