@@ -110,7 +110,7 @@ static __device__ __noinline__ void gen_modulus_zero_lds(const mz_lds_t* in_lds,
   long long a = 0;
   bool bad = false;
 #pragma unroll
-  for (int d = 0; d < 32; d++) {
+  for (int d = 0; d < 32; d++) {  // (unrolled: rolled it is 5 % slower for the row kernels and frees no registers they need)
     long long cd = d < 31 ? in(d) : 0;
 #pragma unroll
     for (int i = 0; i < 17; i++) {
@@ -138,6 +138,82 @@ __device__ __forceinline__ void gen_modulus_zero(const long long* in, long long*
 #pragma unroll
   for (int i = 0; i < 31; i++) l[i * MZ_LANES] = in[i];
   gen_modulus_zero_lds(l, trace, N, row, col0, err);
+}
+
+// ---- row-kernel helpers: packed limbs, limb products accumulated in LDS -------------------------------------------------------
+// The sixteen 16-bit limbs of a coordinate are kept two to a register (P16).  The 31-coefficient polynomial of a witness block lives
+// in the lane's LDS slots (the argument buffer of gen_modulus_zero_lds, trace_common.h); a limb product is a called function that
+// unpacks its operands, forms the 31 coefficients in its own registers and adds them to the slots.  The row kernel itself then
+// holds little more than its packed coordinates.  (Round 2, k_g2_rows: fourteen unpacked arrays and two or three polynomials:
+// 256 + 256 registers and 784 B of scratch per lane.)
+struct P16 {
+  u32 w[8];
+};
+__device__ __forceinline__ P16 p16_pack(const fq& m) {
+  const fqw cw = fq_to_canonical(m);
+  P16 p;
+#pragma unroll
+  for (int i = 0; i < 8; i++) p.w[i] = (u32)(cw.l[i >> 1] >> (32 * (i & 1)));
+  return p;
+}
+__device__ __forceinline__ void p16_unpack(const P16& p, int* l) {
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    l[2 * i] = (int)(p.w[i] & 0xFFFF);
+    l[2 * i + 1] = (int)(p.w[i] >> 16);
+  }
+}
+// slots += coef * (x - [mode 1] sub) * (y - [mode 2] sub) as limb polynomials; cm = coef * 4 + mode.  The packed operands travel as
+// vector-typed arguments (registers; a struct argument of this size goes through the stack, i.e. scratch memory).
+typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+static __device__ __noinline__ void mac_lds_v(mz_lds_t* slots, int cm, u32x4 xa, u32x4 xb, u32x4 ya, u32x4 yb, u32x4 sa, u32x4 sb) {
+  const int mode = cm & 3, coef = cm >> 2;
+  int a[16], b[16], t[16];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    a[2 * i] = (int)(xa[i] & 0xFFFF);
+    a[2 * i + 1] = (int)(xa[i] >> 16);
+    a[8 + 2 * i] = (int)(xb[i] & 0xFFFF);
+    a[8 + 2 * i + 1] = (int)(xb[i] >> 16);
+    b[2 * i] = (int)(ya[i] & 0xFFFF);
+    b[2 * i + 1] = (int)(ya[i] >> 16);
+    b[8 + 2 * i] = (int)(yb[i] & 0xFFFF);
+    b[8 + 2 * i + 1] = (int)(yb[i] >> 16);
+    t[2 * i] = (int)(sa[i] & 0xFFFF);
+    t[2 * i + 1] = (int)(sa[i] >> 16);
+    t[8 + 2 * i] = (int)(sb[i] & 0xFFFF);
+    t[8 + 2 * i + 1] = (int)(sb[i] >> 16);
+  }
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    a[i] -= mode == 1 ? t[i] : 0;
+    b[i] -= mode == 2 ? t[i] : 0;
+    a[i] *= coef;
+  }
+  long long out[31];
+#pragma unroll
+  for (int i = 0; i < 31; i++) out[i] = 0;
+#pragma unroll
+  for (int i = 0; i < 16; i++)
+#pragma unroll
+    for (int j = 0; j < 16; j++) out[i + j] += (long long)a[i] * b[j];
+#pragma unroll
+  for (int i = 0; i < 31; i++) slots[i * MZ_LANES] += out[i];
+}
+__device__ __forceinline__ void mac_lds(mz_lds_t* slots, int cm, const P16& x, const P16& y, const P16& sub) {
+  mac_lds_v(slots, cm, u32x4{x.w[0], x.w[1], x.w[2], x.w[3]}, u32x4{x.w[4], x.w[5], x.w[6], x.w[7]}, u32x4{y.w[0], y.w[1], y.w[2], y.w[3]},
+            u32x4{y.w[4], y.w[5], y.w[6], y.w[7]}, u32x4{sub.w[0], sub.w[1], sub.w[2], sub.w[3]},
+            u32x4{sub.w[4], sub.w[5], sub.w[6], sub.w[7]});
+}
+__device__ __forceinline__ void lin_lds(mz_lds_t* slots, int coef, const P16& x) {
+  int a[16];
+  p16_unpack(x, a);
+#pragma unroll
+  for (int i = 0; i < 16; i++) slots[i * MZ_LANES] += (long long)(coef * a[i]);
+}
+__device__ __forceinline__ void zero_lds(mz_lds_t* slots) {
+#pragma unroll
+  for (int i = 0; i < 31; i++) slots[i * MZ_LANES] = 0;
 }
 
 __device__ __forceinline__ void pol_mul16(const int* a, const int* b, long long* out /*31*/) {

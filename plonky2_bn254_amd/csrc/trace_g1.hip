@@ -352,104 +352,99 @@ __global__ __launch_bounds__(64) void k_g1_rows(const u64* __restrict__ scalars,
   for (int i = 0; i < 4; i++) s[i] = scalars[4 * inst + i];
   const bool bitk = (s[k >> 6] >> (k & 63)) & 1;
 
-  AffPt a, b, c, sum, dbl;
-  if (adding) {
-    a = affine_pt(px, py, zi, cnt, (size_t)sum_point(s, k) * n + inst);
-    b = affine_pt(px, py, zi, cnt, (size_t)(257 + k) * n + inst);
-    c = affine_pt(px, py, zi, cnt, (size_t)(1 + k) * n + inst);
-    dbl = b;
-    sum = bitk ? c : a;
-  } else {
-    a = affine_pt(px, py, zi, cnt, (size_t)(257 + k) * n + inst);
-    b = a;
-    c = affine_pt(px, py, zi, cnt, (size_t)(258 + k) * n + inst);
-    dbl = c;
-    sum = affine_pt(px, py, zi, cnt, (size_t)sum_point(s, k + 1) * n + inst);
-  }
-  const fq di = ld_fq(deninv, nrows, r);
-  const bool x_eq = fq_eq(a.x, b.x);
-  fq lambda, inv;
-  if (!x_eq) {
-    lambda = fq_mul(fq_sub(b.y, a.y), di);  // add.rs:66
-    inv = di;
-  } else {
-    fq xx = fq_sqr(a.x);
-    lambda = fq_mul(fq_add(fq_dbl(xx), xx), di);  // 3x^2 / 2y, add.rs:80
-    inv = fq_zero();
-  }
-
+  // Three affine points per row, one after the other (packed into limbs at once, trace_common.h):  P1 = the running sum S (S_(k-1) on
+  // an adding row, S_k on a doubling row), P2 = D_k, P3 = C_k (adding) or D_(k+1) (doubling).   adding: a = P1, b = P2, c = P3,
+  // double = P2, sum = bit ? P3 : P1;   doubling: a = b = P2, c = P3, double = P3, sum = P1.
   auto put = [&](int col, u64 v) { trace[(size_t)col * N + r] = v; };
-  int ax[16], ay[16], bx[16], by[16], cx[16], cy[16], lam[16], invl[16], t16[16];
-  fq_to_limbs(a.x, ax);
-  fq_to_limbs(a.y, ay);
-  fq_to_limbs(b.x, bx);
-  fq_to_limbs(b.y, by);
-  fq_to_limbs(c.x, cx);
-  fq_to_limbs(c.y, cy);
-  fq_to_limbs(lambda, lam);
-  fq_to_limbs(inv, invl);
+  auto put_p = [&](int col, const P16& p) {
 #pragma unroll
-  for (int i = 0; i < 16; i++) {
-    put(G1_COL_A + i, ax[i]);
-    put(G1_COL_A + 16 + i, ay[i]);
-    put(G1_COL_B + i, bx[i]);
-    put(G1_COL_B + 16 + i, by[i]);
-    put(G1_COL_C + i, cx[i]);
-    put(G1_COL_C + 16 + i, cy[i]);
-    put(G1_COL_AUX + G1_AUX_LAMBDA + i, lam[i]);
-    put(G1_COL_AUX + G1_AUX_IS_X_EQ_AUX + i, invl[i]);
+    for (int i = 0; i < 8; i++) {
+      put(col + 2 * i, (u64)(p.w[i] & 0xFFFF));
+      put(col + 2 * i + 1, (u64)(p.w[i] >> 16));
+    }
+  };
+  auto sel = [&](bool first, const P16& x, const P16& y) {
+    P16 o;
+#pragma unroll
+    for (int i = 0; i < 8; i++) o.w[i] = first ? x.w[i] : y.w[i];
+    return o;
+  };
+  P16 ax, ay, bx, by, lam, invl, s1x, s1y;
+  bool x_eq;
+  {
+    const AffPt p1 = affine_pt(px, py, zi, cnt, (size_t)sum_point(s, adding ? k : k + 1) * n + inst);
+    const AffPt p2 = affine_pt(px, py, zi, cnt, (size_t)(257 + k) * n + inst);
+    AffPt a = p2;
+    if (adding) a = p1;
+    const AffPt& b = p2;
+    const fq di = ld_fq(deninv, nrows, r);
+    x_eq = fq_eq(a.x, b.x);
+    fq lambda, inv;
+    if (!x_eq) {
+      lambda = fq_mul(fq_sub(b.y, a.y), di);  // add.rs:66
+      inv = di;
+    } else {
+      fq xx = fq_sqr(a.x);
+      lambda = fq_mul(fq_add(fq_dbl(xx), xx), di);  // 3x^2 / 2y, add.rs:80
+      inv = fq_zero();
+    }
+    ax = p16_pack(a.x); ay = p16_pack(a.y); bx = p16_pack(b.x); by = p16_pack(b.y);
+    lam = p16_pack(lambda); invl = p16_pack(inv);
+    s1x = p16_pack(p1.x); s1y = p16_pack(p1.y);
   }
-  fq_to_limbs(dbl.x, t16);
-#pragma unroll
-  for (int i = 0; i < 16; i++) put(G1_COL_DOUBLE + i, t16[i]);
-  fq_to_limbs(dbl.y, t16);
-#pragma unroll
-  for (int i = 0; i < 16; i++) put(G1_COL_DOUBLE + 16 + i, t16[i]);
-  fq_to_limbs(sum.x, t16);
-#pragma unroll
-  for (int i = 0; i < 16; i++) put(G1_COL_SUM + i, t16[i]);
-  fq_to_limbs(sum.y, t16);
-#pragma unroll
-  for (int i = 0; i < 16; i++) put(G1_COL_SUM + 16 + i, t16[i]);
-
+  put_p(G1_COL_A, ax); put_p(G1_COL_A + 16, ay);
+  put_p(G1_COL_B, bx); put_p(G1_COL_B + 16, by);
+  put_p(G1_COL_AUX + G1_AUX_LAMBDA, lam);
+  put_p(G1_COL_AUX + G1_AUX_IS_X_EQ_AUX, invl);
+  P16 cx, cy;
+  {
+    const AffPt p3 = affine_pt(px, py, zi, cnt, (size_t)(adding ? 1 + k : 258 + k) * n + inst);
+    cx = p16_pack(p3.x);
+    cy = p16_pack(p3.y);
+  }
+  put_p(G1_COL_C, cx); put_p(G1_COL_C + 16, cy);
+  put_p(G1_COL_DOUBLE, sel(adding, bx, cx)); put_p(G1_COL_DOUBLE + 16, sel(adding, by, cy));
+  const bool sum_is_c = adding && bitk;
+  put_p(G1_COL_SUM, sel(sum_is_c, cx, s1x)); put_p(G1_COL_SUM + 16, sel(sum_is_c, cy, s1y));
   const u64 is_x_eq = x_eq ? 1 : 0;
   put(G1_COL_AUX + G1_AUX_IS_X_EQ, is_x_eq);
   put(G1_COL_AUX + G1_AUX_IS_X_EQ_FILTER, is_x_eq);
 
-  int dx[16];
-#pragma unroll
-  for (int i = 0; i < 16; i++) dx[i] = bx[i] - ax[i];
-  __shared__ long long mz_buf[31][MZ_LANES];  // the arguments of gen_modulus_zero (trace_common.h)
-  long long* const mz_slots = &mz_buf[0][threadIdx.x];
-  long long diff[31], tmp[31];
+  __shared__ long long mz_buf[31][MZ_LANES];  // the polynomial of the current witness block (trace_common.h)
+  mz_lds_t* const slots = (mz_lds_t*)&mz_buf[0][threadIdx.x];
+  auto mac = [&](int coef, const P16& x, const P16* xs, const P16& y, const P16* ys) {
+    mac_lds(slots, coef * 4 + (xs ? 1 : ys ? 2 : 0), x, y, xs ? *xs : ys ? *ys : x);
+  };
+  auto emit = [&](int col) { gen_modulus_zero_lds(slots, trace, N, r, col, err); };
   // is_modulus_zero witness: delta_x * inv - 1 + is_zero   (is_modulus_zero.rs:57-59)
-  pol_mul16(dx, invl, diff);
-  diff[0] += (long long)is_x_eq - 1;
-  gen_modulus_zero(diff, mz_slots, trace, N, r, G1_COL_AUX + G1_AUX_IS_X_EQ_AUX + 16, err);
+  zero_lds(slots);
+  mac(1, bx, &ax, invl, nullptr);
+  slots[0] += (long long)is_x_eq - 1;
+  emit(G1_COL_AUX + G1_AUX_IS_X_EQ_AUX + 16);
   // lambda witness
-  if (!x_eq) {
-    pol_mul16(lam, dx, diff);  // lambda*(b.x-a.x) - (b.y-a.y)
-#pragma unroll
-    for (int i = 0; i < 16; i++) diff[i] -= (long long)(by[i] - ay[i]);
-  } else {
-    pol_mul16(lam, ay, diff);  // 2*a.y*lambda - 3*a.x^2
-    pol_mul16(ax, ax, tmp);
-#pragma unroll
-    for (int i = 0; i < 31; i++) diff[i] = 2 * diff[i] - 3 * tmp[i];
+  zero_lds(slots);
+  if (!x_eq) {  // lambda*(b.x-a.x) - (b.y-a.y)
+    mac(1, lam, nullptr, bx, &ax);
+    lin_lds(slots, -1, by);
+    lin_lds(slots, 1, ay);
+  } else {  // 2*a.y*lambda - 3*a.x^2
+    mac(2, lam, nullptr, ay, nullptr);
+    mac(-3, ax, nullptr, ax, nullptr);
   }
-  gen_modulus_zero(diff, mz_slots, trace, N, r, G1_COL_AUX + G1_AUX_LAMBDA_AUX, err);
+  emit(G1_COL_AUX + G1_AUX_LAMBDA_AUX);
   // x witness: lambda^2 - (a.x + b.x + c.x)
-  pol_mul16(lam, lam, diff);
-#pragma unroll
-  for (int i = 0; i < 16; i++) diff[i] -= (long long)(ax[i] + bx[i] + cx[i]);
-  gen_modulus_zero(diff, mz_slots, trace, N, r, G1_COL_AUX + G1_AUX_X_AUX, err);
+  zero_lds(slots);
+  mac(1, lam, nullptr, lam, nullptr);
+  lin_lds(slots, -1, ax);
+  lin_lds(slots, -1, bx);
+  lin_lds(slots, -1, cx);
+  emit(G1_COL_AUX + G1_AUX_X_AUX);
   // y witness: lambda*(c.x - a.x) + c.y + a.y
-#pragma unroll
-  for (int i = 0; i < 16; i++) t16[i] = cx[i] - ax[i];
-  pol_mul16(lam, t16, diff);
-#pragma unroll
-  for (int i = 0; i < 16; i++) diff[i] += (long long)(cy[i] + ay[i]);
-  gen_modulus_zero(diff, mz_slots, trace, N, r, G1_COL_AUX + G1_AUX_Y_AUX, err);
+  zero_lds(slots);
+  mac(1, lam, nullptr, cx, &ax);
+  lin_lds(slots, 1, cy);
+  lin_lds(slots, 1, ay);
+  emit(G1_COL_AUX + G1_AUX_Y_AUX);
 
   // bits rotated left by k (scalar_mul_stark.rs:163-167), flags and bookkeeping columns
   for (int i = 0; i < 256; i++) {
