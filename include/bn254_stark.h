@@ -99,7 +99,7 @@ int bn254s_ctx_trim(bn254s_ctx* ctx);
  * rows = max(2^min_rows_log2, 512 n) rounded up to a power of two; 2^16 .. 2^23 rows (n <= 16384) are supported
  * (a G1 proof of 2^22 rows keeps about 200 GB resident, one of 2^23 rows about 245 GB: its workspace is laid out to fit;
  * a G2 proof of 2^23 rows, whose two LDEs alone would be 296 GB, runs in a streaming workspace that keeps only coefficients
- * resident and recomputes LDE rows where they are needed: 9.2 s, ~250 GB),
+ * resident and recomputes LDE rows where they are needed: 8.0 s, ~250 GB),
  * i.e. one proof can cover all calls of a circuit exactly as Bn254Hook::constrain batches them (hook.rs:63-71). */
 int bn254s_prove_g1(bn254s_ctx* ctx, const bn254s_params* params, const uint64_t* scalars /* n x 4 */,
                     const uint64_t* x /* n x 8 */, const uint64_t* offset /* n x 8 */, size_t n, bn254s_proof** out);

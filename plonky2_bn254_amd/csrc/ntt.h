@@ -41,7 +41,9 @@ void ntt_coset_inverse_tall(const NttTables* T, const NttTallTables* TT, int h, 
                             hipStream_t s);
 void ntt_inverse_lde_tall(const NttTables* T, const NttTallTables* TT, const u64* values, u64* coeffs, u64* lde, u64* tmp, int ncols,
                           hipStream_t s);
-void ntt_lde_tall(const NttTables* T, const NttTallTables* TT, const u64* coeffs, u64* lde, u64* tmp, int ncols, hipStream_t s);
+// coset_mask: bit h set = compute coset h (the lower / upper half of the bit-reversed output); 3 = both
+void ntt_lde_tall(const NttTables* T, const NttTallTables* TT, const u64* coeffs, u64* lde, u64* tmp, int ncols, hipStream_t s,
+                  int coset_mask = 3);
 
 // ---- N = 2^23: one radix-2 level above the tall transforms (see ntt.hip) ---------------------------------------------
 struct NttSplitTables {
@@ -53,7 +55,7 @@ struct NttSplitTables {
 int ntt_split_tables_init(NttSplitTables* S, unsigned log_n);
 void ntt_split_tables_free(NttSplitTables* S);
 void ntt_split_inverse(const NttSplitTables* S, const u64* values, u64* halves, int ncols, hipStream_t s);
-void ntt_split_forward(const NttSplitTables* S, const u64* eo, u64* lde, size_t lde_stride, int ncols, hipStream_t s);
+void ntt_split_forward(const NttSplitTables* S, const u64* eo, u64* lde, size_t lde_stride, int ncols, hipStream_t s, int coset_mask = 3);
 void ntt_coset_inverse_split(const NttTables* T, const NttTallTables* TT, const NttSplitTables* S, int h, const u64* values, u64* coeffs,
                              u64* tmp, int ncols, hipStream_t s);
 

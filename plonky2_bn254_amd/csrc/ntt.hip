@@ -670,11 +670,13 @@ void ntt_inverse_lde_tall(const NttTables* T, const NttTallTables* TT, const u64
   }
 }
 // transposed coefficients[C][N] -> lde[C][2N] bit-reversed; tmp[C][N].
-void ntt_lde_tall(const NttTables* T, const NttTallTables* TT, const u64* coeffs, u64* lde, u64* tmp, int ncols, hipStream_t s) {
+void ntt_lde_tall(const NttTables* T, const NttTallTables* TT, const u64* coeffs, u64* lde, u64* tmp, int ncols, hipStream_t s,
+                  int coset_mask) {
   const unsigned log_r = TT->log_n - 16;
   const size_t N = (size_t)1 << TT->log_n;
   dim3 grid(16, (unsigned)(ncols << log_r)), block(256);
   for (int h = 0; h < 2; h++) {
+    if (!((coset_mask >> h) & 1)) continue;  // (the streaming quotient needs one coset at a time)
     u64* half = lde + (size_t)h * N;
     k_ntt_pass1<false><<<grid, block, 0, s>>>(coeffs, N, half, 2 * N, TT->block_coset_pow[h], T->twmat_fwd, T->tw256_fwd, log_r);
     k_ntt_pass2<false, true><<<grid, block, 0, s>>>(half, 2 * N, tmp, N, nullptr, 1, T->tw256_fwd, log_r);
@@ -711,8 +713,8 @@ __global__ __launch_bounds__(256) void k_split_inv(const u64* __restrict__ in, u
 }
 __global__ __launch_bounds__(256) void k_split_fwd(const u64* __restrict__ eo, u64* __restrict__ out, size_t N, unsigned log_h,
                                                    size_t out_stride, const u64* __restrict__ hi, const u64* __restrict__ lo, u64 shift0,
-                                                   u64 shift1) {
-  const size_t H = N >> 1, i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // i = h H + q < N
+                                                   u64 shift1, size_t i0) {
+  const size_t H = N >> 1, i = i0 + (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // i = h H + q < N
   const u32 h = (u32)(i >> log_h), q = (u32)(i & (H - 1));
   const u64* e = eo + (size_t)blockIdx.y * 2 * N;  // [E (N words) | O (N words)]: the LDEs of the two halves
   const u32 k = bitrev32(q, log_h);
@@ -770,9 +772,15 @@ void ntt_split_inverse(const NttSplitTables* S, const u64* values, u64* halves, 
   k_split_inv<<<dim3((unsigned)(N / 512), ncols), 256, 0, s>>>(values, halves, N, S->inv_hi, S->inv_lo, S->half, S->half);
 }
 // eo[C][2][N] (bit-reversed LDEs of the two halves of each column) -> lde[C][2N] bit-reversed
-void ntt_split_forward(const NttSplitTables* S, const u64* eo, u64* lde, size_t lde_stride, int ncols, hipStream_t s) {
-  const size_t N = (size_t)1 << S->log_n;
-  k_split_fwd<<<dim3((unsigned)(N / 256), ncols), 256, 0, s>>>(eo, lde, N, S->log_n - 1, lde_stride, S->fwd_hi, S->fwd_lo, S->shift[0], S->shift[1]);
+void ntt_split_forward(const NttSplitTables* S, const u64* eo, u64* lde, size_t lde_stride, int ncols, hipStream_t s, int coset_mask) {
+  const size_t N = (size_t)1 << S->log_n, H = N >> 1;
+  if (coset_mask == 3) {
+    k_split_fwd<<<dim3((unsigned)(N / 256), ncols), 256, 0, s>>>(eo, lde, N, S->log_n - 1, lde_stride, S->fwd_hi, S->fwd_lo, S->shift[0], S->shift[1], 0);
+    return;
+  }
+  const int h = coset_mask == 2 ? 1 : 0;  // one coset: the i = h H + q half of the index range
+  k_split_fwd<<<dim3((unsigned)(H / 256), ncols), 256, 0, s>>>(eo, lde, N, S->log_n - 1, lde_stride, S->fwd_hi, S->fwd_lo, S->shift[0], S->shift[1],
+                                                             (size_t)h * H);
 }
 // values on coset h of the N-point domain (natural order) -> the halves of the interpolant's coefficients; TT = tall tables of H
 void ntt_coset_inverse_split(const NttTables* T, const NttTallTables* TT, const NttSplitTables* S, int h, const u64* values, u64* coeffs,

@@ -275,14 +275,16 @@ static int prove_on_slot(bn254s_ctx* c, Slot& sl, int kind, const bn254s_params&
   };
   // stream mode: the LDE of ONE column chunk (coefficients at `coef`, cn <= CH columns) into d_ldechunk
   u64* d_ldechunk_fwd = nullptr;  // (= d_ldechunk once the workspace is set up)
-  auto lde_chunk = [&](const u64* coef, int cn) {
+  // (coset_mask: 1 / 2 = only coset 0 / 1 of the output, 3 = both; under the split level coset h of the N-point domain comes from
+  // coset h of both half transforms)
+  auto lde_chunk = [&](const u64* coef, int cn, int coset_mask = 3) {
     if (log_s) {
       u64* eo = d_tmp_fwd;
       u64* ntmp = d_tmp_fwd + (size_t)CH * 2 * N;
-      ntt_lde_tall(&c->ntt, TT, coef, eo, ntmp, 2 * cn, st);
-      ntt_split_forward(SP, eo, d_ldechunk_fwd, M2, cn, st);
+      ntt_lde_tall(&c->ntt, TT, coef, eo, ntmp, 2 * cn, st, coset_mask);
+      ntt_split_forward(SP, eo, d_ldechunk_fwd, M2, cn, st, coset_mask);
     } else {
-      ntt_lde_tall(&c->ntt, TT, coef, d_ldechunk_fwd, d_tmp_fwd, cn, st);
+      ntt_lde_tall(&c->ntt, TT, coef, d_ldechunk_fwd, d_tmp_fwd, cn, st, coset_mask);
     }
   };
   // stream mode: from_values of a commitment, chunk by chunk: coefficients stay, the chunk's LDE is absorbed by the leaf hash
@@ -581,12 +583,12 @@ static int prove_on_slot(bn254s_ctx* c, Slot& sl, int kind, const bn254s_params&
       for (size_t k0 = 0; k0 < N; k0 += BK) {
         for (int c0 = 0; c0 < W; c0 += CH) {
           const int cn = std::min(CH, W - c0);
-          lde_chunk(d_tcoef + (size_t)c0 * N, cn);
+          lde_chunk(d_tcoef + (size_t)c0 * N, cn, 1 << h);
           fri_extract_window(d_ldechunk, M2, log_n, h, k0, WROWS, cn, d_tw + (size_t)c0 * WROWS, st);
         }
         for (int c0 = 0; c0 < A; c0 += CH) {
           const int cn = std::min(CH, A - c0);
-          lde_chunk(d_acoef + (size_t)c0 * N, cn);
+          lde_chunk(d_acoef + (size_t)c0 * N, cn, 1 << h);
           fri_extract_window(d_ldechunk, M2, log_n, h, k0, WROWS, cn, d_aw + (size_t)c0 * WROWS, st);
         }
         quotient_point_tables_window(d_wpt, d_wpt + WROWS, d_wpt + 2 * WROWS, log_n, h, k0, WROWS, st);
