@@ -306,16 +306,18 @@ static int prove_on_slot(bn254s_ctx* c, Slot& sl, int kind, const bn254s_params&
     }
   };
   // leaf hash of a resident commitment: one GPU-filling section, or (BN254S_HASH_SPLIT, 2^16-row proofs) several shorter ones
-  auto hash_sections = [&](const u64* lde, int width, u64* tree) {
+  auto hash_sections = [&](const u64* lde, int width, u64* tree, int stage) {
     const int S = log_n == 16 ? c->hash_split : 1;
     if (S <= 1) {
       BigSection big(c, st, BIG_HASH);
+      hipEventRecord(sl.events[2 * stage], st);  // (the stage's clock starts once the section is admitted)
       merkle_leaves(lde, 1, M2, width, log_m2_fwd, tree, st);
       return;
     }
     const size_t cnt = M2 / S;
     for (int k = 0; k < S; k++) {
       BigSection big(c, st, BIG_HASH_PART);
+      if (k == 0) hipEventRecord(sl.events[2 * stage], st);
       merkle_leaves_range(lde, 1, M2, width, (size_t)k * cnt, cnt, tree, st);
     }
   };
@@ -488,8 +490,7 @@ static int prove_on_slot(bn254s_ctx* c, Slot& sl, int kind, const bn254s_params&
       do_commit_ntt(d_tvals, d_tcoef, d_tlde, W);
       se(ST_TRACE_NTT);
     }
-    sb(ST_TRACE_MERKLE);
-    hash_sections(d_tlde, W, d_ttree);
+    hash_sections(d_tlde, W, d_ttree, ST_TRACE_MERKLE);
   }
   merkle_upper(log_m2, P.cap_height, d_ttree, st, mmode());
   u64 caps[3][64];
@@ -549,8 +550,7 @@ static int prove_on_slot(bn254s_ctx* c, Slot& sl, int kind, const bn254s_params&
       do_commit_ntt(d_avals, d_acoef, d_alde, A);
       se(ST_AUX_NTT);
     }
-    sb(ST_AUX_MERKLE);
-    hash_sections(d_alde, A, d_atree);
+    hash_sections(d_alde, A, d_atree, ST_AUX_MERKLE);
   }
   merkle_upper(log_m2, P.cap_height, d_atree, st, mmode());
   CHK(hipMemcpyAsync(caps[1], d_atree + cap_off, CAPW * 8, hipMemcpyDeviceToHost, st));
