@@ -26,10 +26,10 @@ __device__ __forceinline__ u64 econv_c1(const u64* x0, const u64* x1, const u64*
 __global__ __launch_bounds__(256) void k_quotient_g2_sched(QArgs A) {
   const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= A.count) return;
-  schedule_part<G2L, false>(A, j, q_next(A, j), 396, 5);
+  schedule_part<G2L, false>(A, j, q_next(A, j), 396, 6);
 }
 
-// Parts 0..4 of eval_g2_add: {is-zero witnesses of delta_x, lambda (x !=), lambda (x ==) + a.y == b.y, x, y}.
+// Parts of eval_g2_add: {0, 5: is-zero witnesses of delta_x.c0 / .c1, 1: lambda (x !=), 2: lambda (x ==) + a.y == b.y, 3: x, 4: y}.
 template <int part>
 __global__ __launch_bounds__(256, 2) void k_quotient_g2_add(QArgs A) {
   typedef G2L L;
@@ -43,52 +43,38 @@ __global__ __launch_bounds__(256, 2) void k_quotient_g2_add(QArgs A) {
   int e = 0;
   const u64 filter = TL(L::FILTER);
   const int AUX = L::AUX;
-  const u64 is_x_eq_filter = TL(AUX + G2_AUX_IS_X_EQ_FILTER);
+  u64 is_x_eq_filter = 0;
+  if constexpr (part == 1 || part == 2) is_x_eq_filter = TL(AUX + G2_AUX_IS_X_EQ_FILTER);
   // An eval_modulus_zero block is linear in its input polynomial, so the terms that are plain trace columns (b.y - a.y, the
   // x coordinates, ...) are summed into the block's accumulator first, one value at a time; only the operands of the Fq2 limb
   // products are ever held as arrays (four of them: 128 registers).  Round 1 held up to eight arrays and spilled.
   auto seed_w = [&](Acc2& sd, int blk, int i, u64 v) { acc2_mad(sd, v, W0[G2_MZ_E0[blk] + 1 + i], W1[G2_MZ_E0[blk] + 1 + i]); };
-  if constexpr (part == 0) {
-    u64 ax0[16], ax1[16], dx0[16], dx1[16], t0[16];
-    ld16(tl, M2, j, L::A, ax0);
-    ld16(tl, M2, j, L::A + 16, ax1);
-    const u64 is_x_eq = TL(AUX + G2_AUX_IS_X_EQ), z0 = TL(AUX + G2_AUX_IS_C0_ZERO), z1 = TL(AUX + G2_AUX_IS_C1_ZERO);
-    EMIT(gl_mul(filter, gl_sub(gl_mul(z0, z1), is_x_eq)));  // e = 0
-    ld16(tl, M2, j, L::B, dx0);
-    ld16(tl, M2, j, L::B + 16, dx1);
-#pragma unroll
-    for (int i = 0; i < 16; i++) {
-      dx0[i] = gl_sub(dx0[i], ax0[i]);
-      dx1[i] = gl_sub(dx1[i], ax1[i]);
+  if constexpr (part == 0 || part == 5) {
+    // the two is-zero witnesses of delta_x are independent blocks over one coordinate each: a kernel of their own each
+    // (parts 0 and 5), two operand arrays live instead of three
+    constexpr int h = part == 0 ? 0 : 1;
+    u64 dx[16], t0[16];
+    const u64 z = TL(AUX + (h ? G2_AUX_IS_C1_ZERO : G2_AUX_IS_C0_ZERO));
+    if constexpr (h == 0) {
+      EMIT(gl_mul(filter, gl_sub(gl_mul(z, TL(AUX + G2_AUX_IS_C1_ZERO)), TL(AUX + G2_AUX_IS_X_EQ))));  // e = 0
     }
-    {
-      ld16(tl, M2, j, AUX + G2_AUX_C0_AUX, t0);  // inv of delta_x.c0
-      const u64 c0 = gl_sub(z0, 1);
-      MZB(0, AUX + G2_AUX_C0_AUX + 16, filter, [&](int i) __attribute__((always_inline)) { u64 v = conv16(dx0, t0, i); return i == 0 ? gl_add(v, c0) : v; });
-      e = 34;
-      Acc2 g;
-      acc2_init(g);
 #pragma unroll
-      for (int i = 0; i < 16; i++) acc2_mad(g, dx0[i], W0[e + i], W1[e + i]);
-      u64 f = gl_mul(filter, z0);
-      tot0 = gl_add(tot0, gl_mul(f, acc_red(g.a0)));
-      tot1 = gl_add(tot1, gl_mul(f, acc_red(g.a1)));
-    }
-    {
-      ld16(tl, M2, j, AUX + G2_AUX_C1_AUX, t0);  // inv of delta_x.c1
-      const u64 c0 = gl_sub(z1, 1);
-      MZB(1, AUX + G2_AUX_C1_AUX + 16, filter, [&](int i) __attribute__((always_inline)) { u64 v = conv16(dx1, t0, i); return i == 0 ? gl_add(v, c0) : v; });
-      e = 83;
-      Acc2 g;
-      acc2_init(g);
+    for (int i = 0; i < 16; i++) dx[i] = gl_sub(TL(L::B + 16 * h + i), TL(L::A + 16 * h + i));
+    ld16(tl, M2, j, AUX + (h ? G2_AUX_C1_AUX : G2_AUX_C0_AUX), t0);  // inv of delta_x.c0 / .c1
+    const u64 c0 = gl_sub(z, 1);
+    MZB(h, AUX + (h ? G2_AUX_C1_AUX : G2_AUX_C0_AUX) + 16, filter, [&](int i) __attribute__((always_inline)) { u64 v = conv16(dx, t0, i); return i == 0 ? gl_add(v, c0) : v; });
+    e = h ? 83 : 34;
+    Acc2 g;
+    acc2_init(g);
 #pragma unroll
-      for (int i = 0; i < 16; i++) acc2_mad(g, dx1[i], W0[e + i], W1[e + i]);
-      u64 f = gl_mul(filter, z1);
-      tot0 = gl_add(tot0, gl_mul(f, acc_red(g.a0)));
-      tot1 = gl_add(tot1, gl_mul(f, acc_red(g.a1)));
+    for (int i = 0; i < 16; i++) acc2_mad(g, dx[i], W0[e + i], W1[e + i]);
+    const u64 f = gl_mul(filter, z);
+    tot0 = gl_add(tot0, gl_mul(f, acc_red(g.a0)));
+    tot1 = gl_add(tot1, gl_mul(f, acc_red(g.a1)));
+    if constexpr (h == 1) {
+      e = 99;
+      EMIT(gl_sub(gl_mul(filter, TL(AUX + G2_AUX_IS_X_EQ)), TL(AUX + G2_AUX_IS_X_EQ_FILTER)));
     }
-    e = 99;
-    EMIT(gl_sub(gl_mul(filter, is_x_eq), is_x_eq_filter));
   } else {
     Acc2 sd0, sd1;
     acc2_init(sd0);
@@ -97,10 +83,7 @@ __global__ __launch_bounds__(256, 2) void k_quotient_g2_add(QArgs A) {
     if constexpr (part == 1) {
       // lambda * delta_x - (b.y - a.y) under filter - is_x_eq_filter
 #pragma unroll 4
-      for (int i = 0; i < 16; i++) {
-        seed_w(sd0, 2, i, gl_sub(TL(L::A + 32 + i), TL(L::B + 32 + i)));
-        seed_w(sd1, 3, i, gl_sub(TL(L::A + 48 + i), TL(L::B + 48 + i)));
-      }
+      for (int i = 0; i < 16; i++) seed_w(sd0, 2, i, gl_sub(TL(L::A + 32 + i), TL(L::B + 32 + i)));
       ld16(tl, M2, j, AUX + G2_AUX_LAMBDA, l0);
       ld16(tl, M2, j, AUX + G2_AUX_LAMBDA + 16, l1);
 #pragma unroll
@@ -110,6 +93,8 @@ __global__ __launch_bounds__(256, 2) void k_quotient_g2_add(QArgs A) {
       }
       const u64 f_ne = gl_sub(filter, is_x_eq_filter);
       MZB(2, AUX + G2_AUX_LAMBDA_AUX, f_ne, [&](int i) __attribute__((always_inline)) { return econv_c0(l0, l1, dx0, dx1, i); }, &sd0);
+#pragma unroll 4
+      for (int i = 0; i < 16; i++) seed_w(sd1, 3, i, gl_sub(TL(L::A + 48 + i), TL(L::B + 48 + i)));
       MZB(3, AUX + G2_AUX_LAMBDA_AUX + 80, f_ne, [&](int i) __attribute__((always_inline)) { return econv_c1(l0, l1, dx0, dx1, i); }, &sd1);
     } else if constexpr (part == 2) {
       // 2 * lambda * a.y - 3 * a.x^2 under is_x_eq_filter, then a.y == b.y
@@ -150,10 +135,7 @@ __global__ __launch_bounds__(256, 2) void k_quotient_g2_add(QArgs A) {
     } else {
       // lambda * (c.x - a.x) + c.y + a.y
 #pragma unroll 4
-      for (int i = 0; i < 16; i++) {
-        seed_w(sd0, 8, i, gl_add(TL(L::C + 32 + i), TL(L::A + 32 + i)));
-        seed_w(sd1, 9, i, gl_add(TL(L::C + 48 + i), TL(L::A + 48 + i)));
-      }
+      for (int i = 0; i < 16; i++) seed_w(sd0, 8, i, gl_add(TL(L::C + 32 + i), TL(L::A + 32 + i)));
       ld16(tl, M2, j, AUX + G2_AUX_LAMBDA, l0);
       ld16(tl, M2, j, AUX + G2_AUX_LAMBDA + 16, l1);
 #pragma unroll
@@ -162,6 +144,8 @@ __global__ __launch_bounds__(256, 2) void k_quotient_g2_add(QArgs A) {
         dx1[i] = gl_sub(TL(L::C + 16 + i), TL(L::A + 16 + i));
       }
       MZB(8, AUX + G2_AUX_Y_AUX, filter, [&](int i) __attribute__((always_inline)) { return econv_c0(l0, l1, dx0, dx1, i); }, &sd0);
+#pragma unroll 4
+      for (int i = 0; i < 16; i++) seed_w(sd1, 9, i, gl_add(TL(L::C + 48 + i), TL(L::A + 48 + i)));
       MZB(9, AUX + G2_AUX_Y_AUX + 80, filter, [&](int i) __attribute__((always_inline)) { return econv_c1(l0, l1, dx0, dx1, i); }, &sd1);
     }
   }
@@ -207,9 +191,10 @@ int fq_quotient_mz_blocks(const int** e0) {
 }
 void g2_quotient_launch(const QArgs& A0, const StarkShape& sh, hipStream_t st) {
   QArgs A = A0;
-  A.n_parts = 6;
+  A.n_parts = 7;
   const unsigned g = (unsigned)((A.count + 255) / 256);
   k_quotient_g2_add<0><<<g, 256, 0, st>>>(A);
+  k_quotient_g2_add<5><<<g, 256, 0, st>>>(A);
   k_quotient_g2_add<1><<<g, 256, 0, st>>>(A);
   k_quotient_g2_add<2><<<g, 256, 0, st>>>(A);
   k_quotient_g2_add<3><<<g, 256, 0, st>>>(A);

@@ -44,9 +44,9 @@ __device__ __forceinline__ void ld16(const u64* __restrict__ tl, size_t M2, size
   for (int i = 0; i < 16; i++) v[i] = tl[(size_t)(col + i) * M2 + j];
 }
 // coefficient i of the limb product A*B (pol_mul_wide), reduced
-// FULL: unrolled completely, operands in registers (G1: three or four operand arrays, no scratch at two waves per SIMD);
-// otherwise the compiler keeps the loops rolled and the operand arrays in private memory with uniform indices (G2, whose
-// eight Fq2 operand arrays do not fit: unrolled completely it spills 0.5-2.4 KB per lane)
+// FULL: forced complete unrolling (G1: three or four operand arrays in registers, no scratch at two waves per SIMD); otherwise
+// the unrolling is left to the compiler's heuristics (G2 / Fq: up to four Fq2 operand arrays; mz_block keeps the coefficients
+// apart with scheduling barriers, which is what holds these kernels inside 256 registers)
 template <bool FULL = false>
 __device__ __forceinline__ u64 conv16(const u64* A, const u64* B, int i) {
   Acc a;
@@ -86,7 +86,10 @@ __device__ __forceinline__ void mz_block(const u64* __restrict__ tl, size_t M2, 
       for (int i = 0; i < 31; i++) acc2_mad(neg, in(i), w0[1 + i], w1[1 + i]);
     } else {
 #pragma unroll
-      for (int i = 0; i < 31; i++) acc2_mad(neg, in(i), w0[1 + i], w1[1 + i]);
+      for (int i = 0; i < 31; i++) {
+        acc2_mad(neg, in(i), w0[1 + i], w1[1 + i]);
+        __builtin_amdgcn_sched_barrier(0);  // one coefficient at a time: interleaved, their partial sums do not fit the registers
+      }
     }
     n0 = acc_red(neg.a0);
     n1 = acc_red(neg.a1);
@@ -239,5 +242,5 @@ void quotient_host_tables(int K, const u64 alphas[2], const int* mz_e0, int n_bl
 void quotient_fill_args(QArgs& A, const StarkShape& sh, const u64* d_tl, const u64* d_al, const u64* d_W, const u64* d_mzt,
                         const QPointTables& pt, const u64 betas[2], const u64 gammas[2], unsigned log_n, u64* d_out,
                         u64* d_part);
-static constexpr int QUOTIENT_MAX_PARTS = 6;
+static constexpr int QUOTIENT_MAX_PARTS = 7;
 void quotient_finish_launch(const QArgs& A, const StarkShape& sh, hipStream_t st);
