@@ -363,7 +363,7 @@ static int prove_on_slot(bn254s_ctx* c, Slot& sl, int kind, const bn254s_params&
   const size_t trace_scr = kind == KIND_G1 ? g1_trace_scratch_words(n) : kind == KIND_G2 ? g2_trace_scratch_words(n) : fq_trace_scratch_words(n);
   u64* d_scr = mem.words("scratch", std::max(trace_scr, aux_scratch_words(sh, N)));
   u64* d_q = mem.words("quot", (size_t)(3 * NQ) * N + (size_t)NQ * M2 + (size_t)QUOTIENT_MAX_PARTS * 2 * (stream ? WROWS : M2));  // qv, ab, qcoef, qlde, partials
-  u64* d_tabs = mem.words("tabs", 2 * (size_t)K + 10 * 2 * 80 + 4 * (size_t)(W + A + NQ));  // W, mzt, apow (8 u32 per power)
+  u64* d_tabs = mem.words("tabs", QUOTIENT_W_WORDS(K) + QUOTIENT_MZT_WORDS + 4 * (size_t)(W + A + NQ));  // W, mzt, apow (8 u32 per power)
   u64* d_open = mem.words("open", std::max((size_t)(W + A + NQ) * NSPL * R * 5 + FRI_OPENING_TABLE_WORDS, n * (size_t)PW));
   // FRI layer values (extension, 2 words) and trees
   size_t fri_words = 0, fri_tree_words = 0;
@@ -432,8 +432,8 @@ static int prove_on_slot(bn254s_ctx* c, Slot& sl, int kind, const bn254s_params&
   u64* d_qlde = d_q + (size_t)3 * NQ * N;   // [4][2N]
   u64* d_qpart = d_qlde + (size_t)NQ * M2;  // [parts][2][2N]
   u64* d_W = d_tabs;
-  u64* d_mzt = d_tabs + 2 * (size_t)K;
-  u64* d_apow = d_mzt + 10 * 2 * 80;
+  u64* d_mzt = d_tabs + QUOTIENT_W_WORDS(K);
+  u64* d_apow = d_mzt + QUOTIENT_MZT_WORDS;
   const size_t cap_off = 4 * merkle_level_offset(log_m2, log_m2 - P.cap_height);
 
   if (sl.events.empty()) {

@@ -21,7 +21,7 @@ static constexpr int G1_MZ_E0[5] = {0, 50, 83, 132, 165};
 
 // Parts 0..4: the five eval_modulus_zero blocks of eval_g1_add (each with the small groups emitted next to it);
 // part 5: the schedule.  One lane per LDE point and part, one launch per part.
-__global__ __launch_bounds__(256) void k_quotient_g1_sched(QArgs A) {
+__global__ __launch_bounds__(256, 2) void k_quotient_g1_sched(QArgs A) {
   const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= A.count) return;
   schedule_part<G1L, false>(A, j, q_next(A, j), 198, 5);
@@ -35,6 +35,7 @@ __global__ __launch_bounds__(256, 2) void k_quotient_g1_add(QArgs A) {
   const u64* __restrict__ tl = A.tl;
   const u64* __restrict__ W0 = A.W;
   const u64* __restrict__ W1 = A.W + A.K;
+  const u32* __restrict__ W3 = (const u32*)(A.W + 2 * (size_t)A.K);  // cut weights (accw_mad)
   u64 tot0 = 0, tot1 = 0;
   int e = 0;
   const int AUX = G1_COL_AUX;
@@ -50,17 +51,17 @@ __global__ __launch_bounds__(256, 2) void k_quotient_g1_add(QArgs A) {
     for (int i = 0; i < 16; i++) u16[i] = gl_sub(u16[i], ax[i]);  // delta_x
     ld16(tl, M2, j, AUX + G1_AUX_IS_X_EQ_AUX, t16);               // inv limbs
     const u64 c0 = gl_sub(is_x_eq, 1);
-    mz_block<true>(tl, M2, j, AUX + G1_AUX_IS_X_EQ_AUX + 16, W0 + G1_MZ_E0[0], W1 + G1_MZ_E0[0], A.mzt + 0 * 160, A.mzt + 0 * 160 + 80,
+    mz_block<true>(tl, M2, j, AUX + G1_AUX_IS_X_EQ_AUX + 16, A, G1_MZ_E0[0], 0,
              filter, [&](int i) __attribute__((always_inline)) { u64 v = conv16<true>(u16, t16, i); return i == 0 ? gl_add(v, c0) : v; }, tot0, tot1);
     e = 33;
-    Acc2 g;
-    acc2_init(g);
+    AccW g;
+    accw_init(g);
 #pragma unroll
-    for (int i = 0; i < 16; i++) acc2_mad(g, u16[i], W0[e + i], W1[e + i]);
+    for (int i = 0; i < 16; i++) accw_mad(g, u16[i], W3 + 8 * (e + i));
     e += 16;
     u64 f = gl_mul(filter, is_x_eq);
-    tot0 = gl_add(tot0, gl_mul(f, acc_red(g.a0)));
-    tot1 = gl_add(tot1, gl_mul(f, acc_red(g.a1)));
+    tot0 = gl_add(tot0, gl_mul(f, acc3_red(g.a0)));
+    tot1 = gl_add(tot1, gl_mul(f, acc3_red(g.a1)));
     EMIT(gl_sub(gl_mul(filter, is_x_eq), is_x_eq_filter));  // e = 49
   } else if constexpr (part == 1) {
     // block 1: lambda*delta_x - (b.y - a.y) under filter - is_x_eq_filter
@@ -70,7 +71,7 @@ __global__ __launch_bounds__(256, 2) void k_quotient_g1_add(QArgs A) {
     for (int i = 0; i < 16; i++) u16[i] = gl_sub(u16[i], ax[i]);  // delta_x
     ld16(tl, M2, j, G1_COL_B + 16, t16);                          // b.y
     ld16(tl, M2, j, G1_COL_A + 16, ax);                           // a.y (a.x no longer needed)
-    mz_block<true>(tl, M2, j, AUX + G1_AUX_LAMBDA_AUX, W0 + G1_MZ_E0[1], W1 + G1_MZ_E0[1], A.mzt + 1 * 160, A.mzt + 1 * 160 + 80,
+    mz_block<true>(tl, M2, j, AUX + G1_AUX_LAMBDA_AUX, A, G1_MZ_E0[1], 1,
              gl_sub(filter, is_x_eq_filter),
              [&](int i) __attribute__((always_inline)) {
                u64 v = conv16<true>(lam, u16, i);
@@ -81,7 +82,7 @@ __global__ __launch_bounds__(256, 2) void k_quotient_g1_add(QArgs A) {
     // block 2: 2*lambda*a.y - 3*a.x^2 under is_x_eq_filter, then a.y == b.y (e = 116..131)
     ld16(tl, M2, j, AUX + G1_AUX_LAMBDA, lam);
     ld16(tl, M2, j, G1_COL_A + 16, u16);  // a.y
-    mz_block<true>(tl, M2, j, AUX + G1_AUX_LAMBDA_AUX, W0 + G1_MZ_E0[2], W1 + G1_MZ_E0[2], A.mzt + 2 * 160, A.mzt + 2 * 160 + 80,
+    mz_block<true>(tl, M2, j, AUX + G1_AUX_LAMBDA_AUX, A, G1_MZ_E0[2], 2,
              is_x_eq_filter,
              [&](int i) __attribute__((always_inline)) {
                u64 ly = conv16<true>(lam, u16, i), xx = conv16<true>(ax, ax, i);
@@ -90,18 +91,18 @@ __global__ __launch_bounds__(256, 2) void k_quotient_g1_add(QArgs A) {
              tot0, tot1);
     e = 116;
     ld16(tl, M2, j, G1_COL_B + 16, t16);
-    Acc2 g;
-    acc2_init(g);
+    AccW g;
+    accw_init(g);
 #pragma unroll
-    for (int i = 0; i < 16; i++) acc2_mad(g, gl_sub(u16[i], t16[i]), W0[e + i], W1[e + i]);
-    tot0 = gl_add(tot0, gl_mul(is_x_eq_filter, acc_red(g.a0)));
-    tot1 = gl_add(tot1, gl_mul(is_x_eq_filter, acc_red(g.a1)));
+    for (int i = 0; i < 16; i++) accw_mad(g, gl_sub(u16[i], t16[i]), W3 + 8 * (e + i));
+    tot0 = gl_add(tot0, gl_mul(is_x_eq_filter, acc3_red(g.a0)));
+    tot1 = gl_add(tot1, gl_mul(is_x_eq_filter, acc3_red(g.a1)));
   } else if constexpr (part == 3) {
     // block 3: lambda^2 - (a.x + b.x + c.x)
     ld16(tl, M2, j, AUX + G1_AUX_LAMBDA, lam);
     ld16(tl, M2, j, G1_COL_B, t16);
     ld16(tl, M2, j, G1_COL_C, u16);
-    mz_block<true>(tl, M2, j, AUX + G1_AUX_X_AUX, W0 + G1_MZ_E0[3], W1 + G1_MZ_E0[3], A.mzt + 3 * 160, A.mzt + 3 * 160 + 80, filter,
+    mz_block<true>(tl, M2, j, AUX + G1_AUX_X_AUX, A, G1_MZ_E0[3], 3, filter,
              [&](int i) __attribute__((always_inline)) {
                u64 v = conv16<true>(lam, lam, i);
                return i < 16 ? gl_sub(v, gl_add(gl_add(ax[i < 16 ? i : 0], t16[i < 16 ? i : 0]), u16[i < 16 ? i : 0])) : v;
@@ -115,7 +116,7 @@ __global__ __launch_bounds__(256, 2) void k_quotient_g1_add(QArgs A) {
     for (int i = 0; i < 16; i++) u16[i] = gl_sub(u16[i], ax[i]);  // c.x - a.x
     ld16(tl, M2, j, G1_COL_C + 16, t16);                          // c.y
     ld16(tl, M2, j, G1_COL_A + 16, ax);                           // a.y
-    mz_block<true>(tl, M2, j, AUX + G1_AUX_Y_AUX, W0 + G1_MZ_E0[4], W1 + G1_MZ_E0[4], A.mzt + 4 * 160, A.mzt + 4 * 160 + 80, filter,
+    mz_block<true>(tl, M2, j, AUX + G1_AUX_Y_AUX, A, G1_MZ_E0[4], 4, filter,
              [&](int i) __attribute__((always_inline)) {
                u64 v = conv16<true>(lam, u16, i);
                return i < 16 ? gl_add(v, gl_add(t16[i < 16 ? i : 0], ax[i < 16 ? i : 0])) : v;
@@ -194,7 +195,7 @@ void quotient_point_tables(u64* d_x, u64* d_lfirst, u64* d_llast, unsigned log_n
 
 // ---- host: alpha-dependent tables ---------------------------------------------------------------------------
 void quotient_host_tables(int K, const u64 alphas[2], const int* mz_e0, int n_blocks, std::vector<u64>& W, std::vector<u64>& mzt) {
-  W.assign(2 * (size_t)K, 0);
+  W.assign(QUOTIENT_W_WORDS(K), 0);
   for (int a = 0; a < 2; a++) {
     u64 v = 1;
     for (int e = K - 1; e >= 0; e--) {
@@ -205,7 +206,7 @@ void quotient_host_tables(int K, const u64 alphas[2], const int* mz_e0, int n_bl
   static const u64 MOD[16] = {64839, 55420, 35862, 15392, 51853, 26737, 27281, 38785,
                               22621, 33153, 17846, 47184, 41001, 57649, 20082, 12388};
   const u64 B = 1ULL << 16, OFF = 1ULL << 29;
-  mzt.assign((size_t)n_blocks * 2 * 80, 0);
+  mzt.assign(QUOTIENT_MZT_WORDS, 0);
   for (int blk = 0; blk < n_blocks; blk++)
     for (int a = 0; a < 2; a++) {
       const u64* w = &W[(size_t)a * K + mz_e0[blk] + 1];  // w[i], i = 0..31: weight of constr_i
@@ -225,6 +226,11 @@ void quotient_host_tables(int K, const u64 alphas[2], const int* mz_e0, int n_bl
       }
       T[79] = gl_mul(OFF, usum);
     }
+  // the same weights cut in 22-bit limbs for accw_mad (quotient_common.h): 8 u32 per term, both alphas side by side
+  for (int e = 0; e < K; e++) w3_store(&W[2 * (size_t)K + 4 * (size_t)e], W[e], W[(size_t)K + e]);
+  for (int blk = 0; blk < n_blocks; blk++)
+    for (int t = 0; t < 80; t++)
+      w3_store(&mzt[QUOTIENT_MZT3_OFF + (size_t)(blk * 80 + t) * 4], mzt[(size_t)(blk * 2) * 80 + t], mzt[(size_t)(blk * 2 + 1) * 80 + t]);
 }
 
 void quotient_fill_args(QArgs& A, const StarkShape& sh, const u64* d_tl, const u64* d_al, const u64* d_W, const u64* d_mzt,

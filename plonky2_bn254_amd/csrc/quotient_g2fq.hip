@@ -21,9 +21,9 @@ __device__ __forceinline__ u64 econv_c1(const u64* x0, const u64* x1, const u64*
 }
 
 #define MZB(blk, auxcol, FILTER, FN, ...) \
-  mz_block(tl, M2, j, (auxcol), W0 + G2_MZ_E0[blk], W1 + G2_MZ_E0[blk], A.mzt + (blk) * 160, A.mzt + (blk) * 160 + 80, (FILTER), FN, tot0, tot1, ##__VA_ARGS__)
+  mz_block(tl, M2, j, (auxcol), A, G2_MZ_E0[blk], (blk), (FILTER), FN, tot0, tot1, ##__VA_ARGS__)
 
-__global__ __launch_bounds__(256) void k_quotient_g2_sched(QArgs A) {
+__global__ __launch_bounds__(256, 2) void k_quotient_g2_sched(QArgs A) {
   const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= A.count) return;
   schedule_part<G2L, false>(A, j, q_next(A, j), 396, 6);
@@ -39,6 +39,7 @@ __global__ __launch_bounds__(256, 2) void k_quotient_g2_add(QArgs A) {
   const u64* __restrict__ tl = A.tl;
   const u64* __restrict__ W0 = A.W;
   const u64* __restrict__ W1 = A.W + A.K;
+  const u32* __restrict__ W3 = (const u32*)(A.W + 2 * (size_t)A.K);  // cut weights (accw_mad)
   u64 tot0 = 0, tot1 = 0;
   int e = 0;
   const u64 filter = TL(L::FILTER);
@@ -64,13 +65,13 @@ __global__ __launch_bounds__(256, 2) void k_quotient_g2_add(QArgs A) {
     const u64 c0 = gl_sub(z, 1);
     MZB(h, AUX + (h ? G2_AUX_C1_AUX : G2_AUX_C0_AUX) + 16, filter, [&](int i) __attribute__((always_inline)) { u64 v = conv16(dx, t0, i); return i == 0 ? gl_add(v, c0) : v; });
     e = h ? 83 : 34;
-    Acc2 g;
-    acc2_init(g);
+    AccW g;
+    accw_init(g);
 #pragma unroll
-    for (int i = 0; i < 16; i++) acc2_mad(g, dx[i], W0[e + i], W1[e + i]);
+    for (int i = 0; i < 16; i++) accw_mad(g, dx[i], W3 + 8 * (e + i));
     const u64 f = gl_mul(filter, z);
-    tot0 = gl_add(tot0, gl_mul(f, acc_red(g.a0)));
-    tot1 = gl_add(tot1, gl_mul(f, acc_red(g.a1)));
+    tot0 = gl_add(tot0, gl_mul(f, acc3_red(g.a0)));
+    tot1 = gl_add(tot1, gl_mul(f, acc3_red(g.a1)));
     if constexpr (h == 1) {
       e = 99;
       EMIT(gl_sub(gl_mul(filter, TL(AUX + G2_AUX_IS_X_EQ)), TL(AUX + G2_AUX_IS_X_EQ_FILTER)));
@@ -113,14 +114,14 @@ __global__ __launch_bounds__(256, 2) void k_quotient_g2_add(QArgs A) {
       MZB(4, AUX + G2_AUX_LAMBDA_AUX, is_x_eq_filter, [&](int i) __attribute__((always_inline)) { return gl_dbl(econv_c0(l0, l1, dx0, dx1, i)); }, &sd0);
       MZB(5, AUX + G2_AUX_LAMBDA_AUX + 80, is_x_eq_filter, [&](int i) __attribute__((always_inline)) { return gl_dbl(econv_c1(l0, l1, dx0, dx1, i)); }, &sd1);
       e = 232;
-      Acc2 g;
-      acc2_init(g);
+      AccW g;
+      accw_init(g);
 #pragma unroll
-      for (int i = 0; i < 16; i++) acc2_mad(g, gl_sub(dx0[i], TL(L::B + 32 + i)), W0[e + i], W1[e + i]);
+      for (int i = 0; i < 16; i++) accw_mad(g, gl_sub(dx0[i], TL(L::B + 32 + i)), W3 + 8 * (e + i));
 #pragma unroll
-      for (int i = 0; i < 16; i++) acc2_mad(g, gl_sub(dx1[i], TL(L::B + 48 + i)), W0[e + 16 + i], W1[e + 16 + i]);
-      tot0 = gl_add(tot0, gl_mul(is_x_eq_filter, acc_red(g.a0)));
-      tot1 = gl_add(tot1, gl_mul(is_x_eq_filter, acc_red(g.a1)));
+      for (int i = 0; i < 16; i++) accw_mad(g, gl_sub(dx1[i], TL(L::B + 48 + i)), W3 + 8 * (e + 16 + i));
+      tot0 = gl_add(tot0, gl_mul(is_x_eq_filter, acc3_red(g.a0)));
+      tot1 = gl_add(tot1, gl_mul(is_x_eq_filter, acc3_red(g.a1)));
     } else if constexpr (part == 3) {
       // lambda^2 - (a.x + b.x + c.x)
 #pragma unroll 4
@@ -152,7 +153,7 @@ __global__ __launch_bounds__(256, 2) void k_quotient_g2_add(QArgs A) {
   store_part(A, part, j, tot0, tot1);
 }
 
-__global__ __launch_bounds__(256) void k_quotient_fq_sched(QArgs A) {
+__global__ __launch_bounds__(256, 2) void k_quotient_fq_sched(QArgs A) {
   const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= A.count) return;
   schedule_part<FQL, true>(A, j, q_next(A, j), 33, 1);
@@ -172,7 +173,7 @@ __global__ __launch_bounds__(256) void k_quotient_fq_mul(QArgs A) {
   ld16(tl, M2, j, L::B, b);
   ld16(tl, M2, j, L::C, c);
   // eval_fq_mul: a*b - c
-  mz_block(tl, M2, j, L::AUX, W0 + FQ_MZ_E0[0], W1 + FQ_MZ_E0[0], A.mzt, A.mzt + 80, filter,
+  mz_block(tl, M2, j, L::AUX, A, FQ_MZ_E0[0], 0, filter,
            [&](int i) __attribute__((always_inline)) {
              u64 v = conv16(a, b, i);
              return i < 16 ? gl_sub(v, c[i < 16 ? i : 0]) : v;

@@ -34,6 +34,9 @@ struct QArgs {
   size_t stride, count, k0;
   u32 natural, hsel;
 };
+// device tables: W = [2][K] weights + [K][8 u32] cut weights; mzt = [10 blocks][2][80] + [10][80][8 u32]
+static constexpr size_t QUOTIENT_MZT3_OFF = 10 * 2 * 80, QUOTIENT_MZT_WORDS = 10 * 2 * 80 + 10 * 80 * 4;
+static inline size_t QUOTIENT_W_WORDS(int K) { return 6 * (size_t)K; }
 __device__ __forceinline__ size_t q_next(const QArgs& A, size_t j) { return A.natural ? j + 1 : next_position(j, A.log_n); }
 
 #define TL(c) tl[(size_t)(c)*M2 + j]
@@ -67,17 +70,24 @@ __device__ __forceinline__ u64 conv16(const u64* A, const u64* B, int i) {
   return acc_red(a);
 }
 
-// One eval_modulus_zero block.  `in(i)` returns coefficient i (0..30) of the input polynomial.
+// One eval_modulus_zero block: first constraint index e0, tables of block `blk`.  `in(i)` returns coefficient i (0..30) of the
+// input polynomial.
 template <bool FULL = false, class InFn>
-__device__ __forceinline__ void mz_block(const u64* __restrict__ tl, size_t M2, size_t j, int auxcol, const u64* __restrict__ w0,
-                                         const u64* __restrict__ w1, const u64* __restrict__ T0, const u64* __restrict__ T1,
+__device__ __forceinline__ void mz_block(const u64* __restrict__ tl, size_t M2, size_t j, int auxcol, const QArgs& A, int e0, int blk,
                                          u64 filter, InFn in, u64& tot0, u64& tot1, const Acc2* seed = nullptr) {
+  const u64* __restrict__ w0 = A.W + e0;
+  const u64* __restrict__ w1 = A.W + A.K + e0;
+  const u64* __restrict__ T0 = A.mzt + (size_t)blk * 160;
+  const u64* __restrict__ T1 = T0 + 80;
+  const u32* __restrict__ w3 = (const u32*)(A.W + 2 * (size_t)A.K) + 8 * (size_t)e0;                   // cut weights (accw_mad)
+  const u32* __restrict__ T3 = (const u32*)(A.mzt + QUOTIENT_MZT3_OFF) + 8 * (size_t)(blk * 80);
   // `seed`: the weighted sum of a part of the input polynomial that the caller accumulated beforehand (the block is linear
   // in its input: terms that need other trace columns than the limb products are summed first, with no operand arrays live)
   // the input polynomial first (its limb products need the most registers), reduced to two field elements before the
   // witness columns of the block are summed
   u64 n0, n1;
   {
+    // (the 128-bit accumulator here: ten registers less than the carry-free one, where the operand arrays leave none)
     Acc2 neg;
     if (seed) neg = *seed;
     else acc2_init(neg);
@@ -94,39 +104,60 @@ __device__ __forceinline__ void mz_block(const u64* __restrict__ tl, size_t M2, 
     n0 = acc_red(neg.a0);
     n1 = acc_red(neg.a1);
   }
-  Acc2 pos, q;
-  acc2_init(pos);
-  acc2_init(q);
+  __builtin_amdgcn_sched_barrier(0);
+  // the witness columns of the block, weights cut in limbs (accw_mad); one accumulator pair live at a time
   const u64 iqp = TL(auxcol + QMZ_IQP);
-  acc2_mad(pos, gl_sub(gl_mul(iqp, iqp), iqp), w0[0], w1[0]);
   const u64 qsign = gl_sub(gl_dbl(iqp), 1);
+  u64 s0, s1;
+  {
+    AccW q;
+    accw_init(q);
 #pragma unroll 1
-  for (int jj = 0; jj < 17; jj++) acc2_mad(q, TL(auxcol + QMZ_QUOT + jj), T0[jj], T1[jj]);
-#pragma unroll 1
-  for (int d = 0; d < 31; d++) {
-    acc2_mad(pos, TL(auxcol + QMZ_LO + d), T0[17 + d], T1[17 + d]);
-    acc2_mad(pos, TL(auxcol + QMZ_HI + d), T0[48 + d], T1[48 + d]);
+    for (int jj = 0; jj < 17; jj++) accw_mad(q, TL(auxcol + QMZ_QUOT + jj), T3 + 8 * jj);
+    s0 = gl_mul(qsign, acc3_red(q.a0));
+    s1 = gl_mul(qsign, acc3_red(q.a1));
   }
-  u64 s0 = gl_add(acc_red(pos.a0), gl_mul(qsign, acc_red(q.a0)));
-  u64 s1 = gl_add(acc_red(pos.a1), gl_mul(qsign, acc_red(q.a1)));
+  __builtin_amdgcn_sched_barrier(0);
+  {
+    AccW pos;
+    accw_init(pos);
+    accw_mad(pos, gl_sub(gl_mul(iqp, iqp), iqp), w3);
+#pragma unroll 1
+    for (int d = 0; d < 31; d++) {
+      accw_mad(pos, TL(auxcol + QMZ_LO + d), T3 + 8 * (17 + d));
+      accw_mad(pos, TL(auxcol + QMZ_HI + d), T3 + 8 * (48 + d));
+    }
+    s0 = gl_add(s0, acc3_red(pos.a0));
+    s1 = gl_add(s1, acc3_red(pos.a1));
+  }
   s0 = gl_sub(gl_sub(s0, T0[79]), n0);
   s1 = gl_sub(gl_sub(s1, T1[79]), n1);
   tot0 = gl_add(tot0, gl_mul(filter, s0));
   tot1 = gl_add(tot1, gl_mul(filter, s1));
+  asm volatile("" : "+v"(tot0), "+v"(tot1));  // (as in EQ_GROUP: the block's sums are folded here, not where the totals are stored)
 }
 
-// sum_i (a[i] - b[i]) * w[e+i] for both alphas, times `filter`
+// sum_i (a[i] - b[i]) * w[e+i] for both alphas, times `filter` (n: a multiple of 16; sixteen differences are formed first so that
+// their thirty-two loads are in flight together, then accumulated with the cut weights)
 #define EQ_GROUP(filter, n, AEXPR, BEXPR)                         \
   {                                                               \
-    Acc2 g_;                                                      \
-    acc2_init(g_);                                                \
-    for (int i = 0; i < (n); i++) {                               \
-      acc2_mad(g_, gl_sub((AEXPR), (BEXPR)), W0[e + i], W1[e + i]); \
+    static_assert((n) % 16 == 0, "EQ_GROUP: n % 16");             \
+    AccW g_;                                                      \
+    accw_init(g_);                                                \
+    constexpr int CH_ = 16;                                       \
+    _Pragma("unroll 1") for (int i0_ = 0; i0_ < (n); i0_ += CH_) { \
+      u64 d_[CH_];                                                \
+      _Pragma("unroll") for (int k_ = 0; k_ < CH_; k_++) {        \
+        const int i = i0_ + k_;                                   \
+        d_[k_] = gl_sub((AEXPR), (BEXPR));                        \
+      }                                                           \
+      _Pragma("unroll") for (int k_ = 0; k_ < CH_; k_++) accw_mad(g_, d_[k_], W3 + 8 * (e + i0_ + k_)); \
     }                                                             \
     e += (n);                                                     \
     u64 f_ = (filter);                                            \
-    tot0 = gl_add(tot0, gl_mul(f_, acc_red(g_.a0)));              \
-    tot1 = gl_add(tot1, gl_mul(f_, acc_red(g_.a1)));              \
+    tot0 = gl_add(tot0, gl_mul(f_, acc3_red(g_.a0)));             \
+    tot1 = gl_add(tot1, gl_mul(f_, acc3_red(g_.a1)));             \
+    asm volatile("" : "+v"(tot0), "+v"(tot1)); /* reduce here: sunk to the end, sixteen groups' column sums stay live */ \
   }
 #define EMIT(c)                                  \
   {                                              \
@@ -154,6 +185,7 @@ __device__ __forceinline__ void schedule_part(const QArgs& A, size_t j, size_t j
   const u64* __restrict__ tl = A.tl;
   const u64* __restrict__ W0 = A.W;
   const u64* __restrict__ W1 = A.W + A.K;
+  const u32* __restrict__ W3 = (const u32*)(A.W + 2 * (size_t)A.K);  // cut weights (accw_mad), 8 u32 per constraint
   const u64 filter = TL(L::FILTER);
   // ---- eval_packed_generic body (scalar_mul_stark.rs:257-339) ------------------------------------------
   const u64 is_first = TL(L::FLAGS + 0), is_last = TL(L::FLAGS + 1);
@@ -228,8 +260,8 @@ __device__ __forceinline__ void finish_point(const QArgs& A, const StarkShape& s
   }
   const u64 x = A.pt.x[j], lfirst = A.pt.lfirst[j], llast = A.pt.llast[j];
   const u64 z_last = gl_sub(x, A.w_inv);
-  lookup_and_ctl_constraints(sh, A.tl, A.al, M2, j, jn, A.W, A.W + A.K, sh.n_constraints, A.betas, A.gammas, lfirst, llast,
-                             z_last, tot0, tot1);
+  lookup_and_ctl_constraints(sh, A.tl, A.al, M2, j, jn, (const u32*)(A.W + 2 * (size_t)A.K), sh.n_constraints, A.betas, A.gammas,
+                             lfirst, llast, z_last, tot0, tot1);
   const size_t h = A.natural ? A.hsel : j >> log_n;
   const size_t k = A.natural ? A.k0 + j : (size_t)bitrev32((u32)(j & (N - 1)), log_n);
   A.out[(0 * 2 + h) * N + k] = gl_mul(tot0, A.zh_inv[h]);
