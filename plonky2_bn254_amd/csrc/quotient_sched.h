@@ -81,10 +81,10 @@ __device__ __forceinline__ void mz_block(const u64* __restrict__ tl, size_t M2, 
   const u64* __restrict__ T1 = T0 + 80;
   const u32* __restrict__ w3 = (const u32*)(A.W + 2 * (size_t)A.K) + 8 * (size_t)e0;                   // cut weights (accw_mad)
   const u32* __restrict__ T3 = (const u32*)(A.mzt + QUOTIENT_MZT3_OFF) + 8 * (size_t)(blk * 80);
-  // `seed`: the weighted sum of a part of the input polynomial that the caller accumulated beforehand (the block is linear
-  // in its input: terms that need other trace columns than the limb products are summed first, with no operand arrays live)
-  // the input polynomial first (its limb products need the most registers), reduced to two field elements before the
-  // witness columns of the block are summed
+  // The input polynomial first (its limb products need the most registers), reduced to two field elements before the witness
+  // columns of the block are summed.  `seed`: the weighted sum of a part of the input polynomial that the caller accumulated
+  // beforehand (the block is linear in its input: terms that need other trace columns than the limb products are summed
+  // first, with no operand arrays live).
   u64 n0, n1;
   {
     // (the 128-bit accumulator here: ten registers less than the carry-free one, where the operand arrays leave none)
