@@ -6,9 +6,10 @@ The compiler's output for the permutation spends a third of its issue slots on r
 script emits the permutation as ONE inline-asm statement with its own register allocation and interleaving:
 
   * lanes are pairs of 32-bit digits (x = x0 + x1 phi, phi = 2^32, phi^2 = phi - 1 mod p), any representative < 2^64;
-  * a product is 4 v_mad_u64_u32 + 3 moves/selects (the carry of the third product goes to an SGPR pair and is re-injected
-    through the high half of the last addend); its reduction is w0 + w1 phi + w2 (phi - 1) - w3 with ONE multiply-add, one
-    64-bit subtraction, three scalar mask operations, three selects and one 64-bit add - exact for every input;
+  * a product is 4 v_mad_u64_u32 + 3 moves (exact code: + a select that re-injects the carry of the third product through the
+    high half of the last addend); its reduction is w0 + w1 phi + w2 (phi - 1) - w3 with ONE multiply-add, one 64-bit
+    subtraction, three scalar mask operations, three selects and one 64-bit add - exact for every input; the fast code
+    (mul_task) is 13 instructions: the carry of the third product is the borrow-in of the final 64-bit subtraction;
   * the MDS layer is 290 v_mad_u64_u32 into 24 64-bit digit sums whose initial values are the next round's constants (no
     constant is ever "added"), an output al + ah phi is folded exactly with one multiply-add (al + ah1 (phi - 1)), one add
     with carry-out, one select and one 64-bit add;
@@ -143,6 +144,26 @@ def mul_task(a, b, dst, t, cA, cB, cT):
     a0, a1 = a
     b0, b1 = b
     Pp, T, Q, R, Sx = t, t + 2, t + 4, t + 6, t + 8
+    if MODE["fast"]:
+        # 13 instructions.  v[t+5] == 0 throughout as well: the carry of the third product is not put into the high half of the
+        # last addend (a select) but taken as the borrow-in of the final subtraction, whose two borrow instructions replace
+        # the select / subtract / sign-extension / 64-bit add of the 14-instruction form:
+        #   t = V + w2 (2^32 - 1) (carry c), t += c ? 2^32 - 1 : 0 (cannot wrap), dst = t - w3 - carry3 as a 64-bit subtraction.
+        # Not covered: c = 0 and t < w3 + carry3 (an underflow), excluded when t >= 2^32 (running min of t.hi, as before).
+        yield ("mad", vp(Pp), "vcc", v(a0), v(b0), 0)
+        yield ("mov", v(T), v(Pp + 1))
+        yield ("mad", vp(Sx), "vcc", v(a0), v(b1), vp(T))
+        yield ("mad", vp(R), sp(cA), v(a1), v(b0), vp(Sx))     # carry3 -> cA, kept until the subtraction
+        yield ("mov", v(Q), v(R + 1))                      # U = (R1, 0)
+        yield ("mov", v(Pp + 1), v(R))                     # V = (w0, w1)
+        yield ("mad", vp(Sx), "vcc", v(a1), v(b1), vp(Q))  # (w2, w3 without carry3)
+        yield ("mad", vp(R), sp(cB), v(Sx), -1, vp(Pp))    # t = V + w2 * (2^32 - 1), carry c -> cB
+        yield ("min", v(MN_R), v(MN_R), v(R + 1))
+        yield ("cnd", v(Q), 0, -1, sp(cB))                 # e
+        yield ("add64", vp(R), vp(R), vp(Q))               # t + e
+        yield ("subbco", v(dst), sp(cA), v(R), v(Sx + 1), sp(cA))
+        yield ("subbco", v(dst + 1), sp(cA), v(R + 1), 0, sp(cA))
+        return
     yield ("mad", vp(Pp), "vcc", v(a0), v(b0), 0)
     yield ("mov", v(T), v(Pp + 1))
     yield ("mad", vp(Q), "vcc", v(a0), v(b1), vp(T))
@@ -152,16 +173,6 @@ def mul_task(a, b, dst, t, cA, cB, cT):
     yield ("cnd", v(Q + 1), 0, 1, sp(cA))              # U.hi = carry of the third product
     yield ("mad", vp(Sx), "vcc", v(a1), v(b1), vp(Q))  # S = (w2, w3)
     yield ("mad", vp(R), sp(cB), v(Sx), -1, vp(Pp))    # t = V + w2 * (2^32 - 1), carry c -> cB
-    if MODE["fast"]:
-        # + (e - w3) as a sign-extended 64-bit addend, e = c ? 2^32 - 1 : 0; not covered: c = 0 and t < w3 (an underflow),
-        # excluded when t >= 2^32 (running min of t.hi -> the check after the permutation).  Measured on gfx950: what counts
-        # is the NUMBER of instructions (every kind costs about four cycles in this mix), so this is the shortest form.
-        yield ("min", v(MN_R), v(MN_R), v(R + 1))
-        yield ("cnd", v(Q), 0, -1, sp(cB))             # e
-        yield ("subco", v(Q), sp(cA), v(Q), v(Sx + 1))     # low word of e - w3, borrow -> cA
-        yield ("cnd", v(Q + 1), 0, -1, sp(cA))         # high word: the sign extension
-        yield ("add64", vp(dst), vp(R), vp(Q))
-        return
     yield ("subco", v(R), sp(cA), v(R), v(Sx + 1))     # t' = t - w3 ...
     yield ("subbco", v(R + 1), sp(cA), v(R + 1), 0, sp(cA))   # ... borrow b -> cA
     yield ("s_xor", sp(cT), sp(cA), sp(cB))
@@ -254,6 +265,8 @@ def rezero_stream_temps(p, streams):
     """The MDS digit sums overlay the S-box temporaries: restore the zero high halves of the T pairs."""
     for s in streams:
         p.emit("mov", v(TMP + s * STREAM_REGS + 3), 0)
+        if MODE["fast"]:
+            p.emit("mov", v(TMP + s * STREAM_REGS + 5), 0)     # the high half of the U pair (mul_task, fast code)
 
 
 def prefetch_next(p):
