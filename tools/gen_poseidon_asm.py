@@ -10,7 +10,7 @@ script emits the permutation as ONE inline-asm statement with its own register a
     high half of the last addend); its reduction is w0 + w1 phi + w2 (phi - 1) - w3 with ONE multiply-add, one 64-bit
     subtraction, three scalar mask operations, three selects and one 64-bit add - exact for every input; the fast code
     (mul_task) is 13 instructions: the carry of the third product is the borrow-in of the final 64-bit subtraction;
-  * the MDS layer is 290 v_mad_u64_u32 into 24 64-bit digit sums whose initial values are the next round's constants (no
+  * the MDS layer is 288 v_mad_u64_u32 into 24 64-bit digit sums whose initial values are the next round's constants (no
     constant is ever "added"), an output al + ah phi is folded exactly with one multiply-add (al + ah1 (phi - 1)), one add
     with carry-out, one select and one 64-bit add;
   * the S-boxes of a full round run three at a time, the S-box of a partial round is interleaved with the 176
@@ -45,7 +45,7 @@ STREAM_REGS = 16
 E0 = TMP + N_STREAMS * STREAM_REGS     # two pairs (e, 0): the "+ (2^32 - 1) if carry" addends of the exact code
 MN_A = TMP + N_STREAMS * STREAM_REGS - 2    # fast code: running min of the low digits al0 (fold needs al0 >= 2^10 > ah1) ...
 MX_A = TMP + N_STREAMS * STREAM_REGS - 1    # ... running max of ah0 (fold needs ah0 + al1 + ah1 < 2^32): the two registers the last
-MN_R = E0 + 4                          # stream does not use (its X3 aliases X2); running min of t.hi (reduction)
+MN_R = E0 + 4                          # stream does not use (its X3 aliases X2); (unused since the products' check became scalar: S_FLAG)
 V_END = E0 + 5
 MODE = {"fast": True}
 A = [(A0 + 2 * i, A0 + 2 * i + 1) for i in range(12)]
@@ -54,6 +54,7 @@ LD0 = 10           # v10..v25: staging of the next chunk's eight loads (sponge s
 SB_LOOP = 24       # s[24:29]: column pointer, column stride in bytes, element index, leaf length (sponge statement)
 S_BLK = 20         # s[20:21]: pointer to the records of the merged partial-round blocks
 SB_MASK = (30, 34, 22)    # s[30:31], s[34:35], s[22:23]: one scratch mask pair per stream (s32, s33 stay untouched)
+S_FLAG = 30               # fast code: s[30:31] (a mask pair only the exact code uses) = sticky underflow flag of the products
 SB_CARRY = 36      # s[36:47]: two carry pairs per stream; the folds use the first four pairs
 SB_CONST = 48      # s[48:95]: the 48 dwords of one round of initial digit sums (or round 0's 12 constants)
 S_PTR = 96         # s[96:97]: running pointer into the table
@@ -135,7 +136,7 @@ def round_robin(tasks):
 
 def mul_task(a, b, dst, t, cA, cB, cT):
     """(a0,a1) x (b0,b1) -> dst pair, any representative below 2^64 (exact code: always; fast code: unless the running min
-    MN_R reaches 0).  a, b: (lo reg, hi reg); t: base of 10 stream
+    S_FLAG is raised).  a, b: (lo reg, hi reg); t: base of 10 stream
     temporaries with v[t+3] == 0 throughout; cA, cB, cT: three SGPR pairs of the stream.  Yields instructions one at a time so
     that several products can be interleaved.
     product (w0..w3 32-bit words) = P0 | R0 | S0 | S1 from four multiply-adds; reduction X = w0 + w1 phi + w2 (phi - 1) - w3:
@@ -149,7 +150,8 @@ def mul_task(a, b, dst, t, cA, cB, cT):
         # last addend (a select) but taken as the borrow-in of the final subtraction, whose two borrow instructions replace
         # the select / subtract / sign-extension / 64-bit add of the 14-instruction form:
         #   t = V + w2 (2^32 - 1) (carry c), t += c ? 2^32 - 1 : 0 (cannot wrap), dst = t - w3 - carry3 as a 64-bit subtraction.
-        # Not covered: c = 0 and t < w3 + carry3 (an underflow), excluded when t >= 2^32 (running min of t.hi, as before).
+        # Not covered: c = 0 and t < w3 + carry3 (an underflow): that is exactly the borrow-out of the last instruction, which a
+        # scalar OR collects in S_FLAG for the check after the permutation (no vector instruction spent on the check).
         yield ("mad", vp(Pp), "vcc", v(a0), v(b0), 0)
         yield ("mov", v(T), v(Pp + 1))
         yield ("mad", vp(Sx), "vcc", v(a0), v(b1), vp(T))
@@ -158,11 +160,11 @@ def mul_task(a, b, dst, t, cA, cB, cT):
         yield ("mov", v(Pp + 1), v(R))                     # V = (w0, w1)
         yield ("mad", vp(Sx), "vcc", v(a1), v(b1), vp(Q))  # (w2, w3 without carry3)
         yield ("mad", vp(R), sp(cB), v(Sx), -1, vp(Pp))    # t = V + w2 * (2^32 - 1), carry c -> cB
-        yield ("min", v(MN_R), v(MN_R), v(R + 1))
         yield ("cnd", v(Q), 0, -1, sp(cB))                 # e
         yield ("add64", vp(R), vp(R), vp(Q))               # t + e
         yield ("subbco", v(dst), sp(cA), v(R), v(Sx + 1), sp(cA))
         yield ("subbco", v(dst + 1), sp(cA), v(R + 1), 0, sp(cA))
+        yield ("s_or", sp(S_FLAG), sp(S_FLAG), sp(cA))     # the final borrow IS the underflow: sticky flag (a scalar instruction)
         return
     yield ("mad", vp(Pp), "vcc", v(a0), v(b0), 0)
     yield ("mov", v(T), v(Pp + 1))
@@ -197,9 +199,7 @@ def sbox_task(x, dst, stream):
 
 def mds_terms(j, lane0_last):
     """(coefficient, source lane) of output j, optionally with the lane-0 terms at the end."""
-    terms = [(MDS_CIRC[i], (i + j) % 12) for i in range(12)]
-    if j == 0:
-        terms.append((8, 0))
+    terms = [(MDS_CIRC[i] + (8 if i == j == 0 else 0), (i + j) % 12) for i in range(12)]     # (the diagonal 8 s_0 merged into row 0)
     if lane0_last:
         terms = [t for t in terms if t[1] != 0] + [t for t in terms if t[1] == 0]
     return terms
@@ -543,7 +543,8 @@ def permutation_body(p, tag=""):
 def flags_init(p):
     p.emit("mov", v(MN_A), -1)
     p.emit("mov", v(MX_A), 0)
-    p.emit("mov", v(MN_R), -1)
+    p.emit("s_mov", S_FLAG, 0)
+    p.emit("s_mov", S_FLAG + 1, 0)
 
 
 def build_permute():
@@ -737,7 +738,7 @@ def run(ins, mem, state, leaf=None, stats=None):
             m.v[E0 + 1] = m.v[E0 + 3] = 0
         elif op == "flagcheck":
             stats["checks"] = stats.get("checks", 0) + 1
-            if not (m.v[MN_A] < 1024 or m.v[MX_A] > 0xFFFFFBFF or m.v[MN_R] == 0 or stats.get("force")):
+            if not (m.v[MN_A] < 1024 or m.v[MX_A] > 0xFFFFFBFF or (m.s[S_FLAG] | m.s[S_FLAG + 1]) != 0 or stats.get("force")):
                 pc = labels[t[1]]
             else:
                 stats["repeats"] = stats.get("repeats", 0) + 1
@@ -795,6 +796,8 @@ def run(ins, mem, state, leaf=None, stats=None):
             m.wr(t[1], m.rd(t[2]) ^ m.rd(t[3]))
         elif op == "s_and":
             m.wr(t[1], m.rd(t[2]) & m.rd(t[3]))
+        elif op == "s_or":
+            m.wr(t[1], m.rd(t[2]) | m.rd(t[3]))
         elif op == "cmplt64":
             m.wr(t[1], 1 if m.rd(t[2]) < m.rd(t[3]) else 0)
         elif op in ("mov", "mov64"):
@@ -878,8 +881,7 @@ def text(ins):
             L.append("s_mov_b64 s[%d:%d], vcc" % (SB_CARRY, SB_CARRY + 1))
             L.append("v_cmp_lt_u32 vcc, 0xfffffbff, v%d" % MX_A)
             L.append("s_or_b64 s[%d:%d], s[%d:%d], vcc" % (SB_CARRY, SB_CARRY + 1, SB_CARRY, SB_CARRY + 1))
-            L.append("v_cmp_eq_u32 vcc, 0, v%d" % MN_R)
-            L.append("s_or_b64 vcc, vcc, s[%d:%d]" % (SB_CARRY, SB_CARRY + 1))
+            L.append("s_or_b64 vcc, s[%d:%d], s[%d:%d]" % (S_FLAG, S_FLAG + 1, SB_CARRY, SB_CARRY + 1))
             L.append("s_cbranch_vccz Lpos_%s_%%=" % t[1])
         elif op == "lds_save":
             for i in range(12):
@@ -970,6 +972,8 @@ def text(ins):
             L.append("s_xor_b64 %s, %s, %s" % tuple(fmt(a) for a in t[1:]))
         elif op == "s_and":
             L.append("s_and_b64 %s, %s, %s" % tuple(fmt(a) for a in t[1:]))
+        elif op == "s_or":
+            L.append("s_or_b64 %s, %s, %s" % tuple(fmt(a) for a in t[1:]))
         elif op == "s_mov":
             L.append("s_mov_b32 s%d, %d" % (t[1], t[2]))
         elif op == "s_ptr":
