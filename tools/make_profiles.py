@@ -50,7 +50,7 @@ def main():
     per_perm = valu_per_wave / 98
     alu = {"leaf_hash_valu_wave_insts_per_launch_781x2e17": 2048 * valu_per_wave, "valu_insts_per_permutation": round(per_perm, 1),
            "salu_insts_per_permutation": round(salu_per_wave / 98, 1),
-           "full_rate_share": 0.1576,   # tools/gen_poseidon_asm.py: 2024 of the 12846 instructions are v_mov_b32 / v_sub_u32 / v_min_u32
+           "full_rate_share": 0.1323,   # tools/gen_poseidon_asm.py: 1576 of the 11908 instructions are v_mov_b32 / v_sub_u32
            "valu_peak_wave_insts_per_s": peak, "peak_definition": "1024 SIMDs x 2.4 GHz / %.2f cycles: issue cost of v_mad_u64_u32 (and of "
            "every other half-rate instruction) measured with 8 waves per SIMD, tools/ubench/sgpr_ops.hip" % mad8,
            "source": "profiles/%s_valu_insts.md" % R}
